@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+        return cache[name]
+    return load
+
+
+def rel_err(a, b, floor=1e-6):
+    """max |a-b| / max(|b|, floor-scaled magnitude): the 'relative fp32' measure used in all parity tests."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), 'NaN positions differ'
+    m = ~nan_b
+    if not m.any():
+        return 0.0
+    scale = np.maximum(np.abs(b[m]), floor + 1e-3 * np.abs(b[m]).max())
+    return float((np.abs(a[m] - b[m]) / scale).max())

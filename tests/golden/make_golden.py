@@ -1,0 +1,456 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What it does: imports the reference's own modules
+(run_nerf_helpers.py, run_nerf.py, nerf_to_coord.py, model/GaussNet.py) with empty in-memory
+stub modules for the I/O-only packages that are absent here (imageio, cv2, configargparse,
+wandb, torchvision), feeds them the deterministic inputs of tests/synth.py and stores
+inputs + outputs as small .npz fixtures. Only DATA is written; no reference source is copied.
+
+The 8-NN procedure (create_index_and_dist.py:126-145) cannot be imported (device and paths
+are hard coded at CI:30-44), so its 12 arithmetic lines are re-issued here around the same
+torch.cdist / sort / gather calls; the fixture is labelled "ref_procedure".
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('NERFAIL_REFERENCE', '/root/reference')
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import synth  # noqa: E402
+
+sys.dont_write_bytecode = True
+for name in ('imageio', 'cv2', 'configargparse', 'wandb'):
+    sys.modules.setdefault(name, types.ModuleType(name))
+tv = types.ModuleType('torchvision')
+tvt = types.ModuleType('torchvision.transforms')
+
+
+class _Resize(torch.nn.Module):  # never executed: model_name == "my_model" skips Resize (GN:147)
+    def __init__(self, size):
+        super().__init__()
+        self.size = size
+
+    def forward(self, x):
+        return torch.nn.functional.interpolate(x, size=self.size, mode='bilinear', align_corners=False)
+
+
+tvt.Resize = _Resize
+tv.transforms = tvt
+sys.modules.setdefault('torchvision', tv)
+sys.modules.setdefault('torchvision.transforms', tvt)
+
+sys.path.insert(0, os.path.join(REF, 'Create_spatial_point_set', 'nerf_pytorch'))
+sys.path.insert(0, os.path.join(REF, 'Create_spatial_point_set'))
+sys.path.insert(0, REF)
+
+import run_nerf_helpers as RH  # noqa: E402  (reference)
+import run_nerf as RN  # noqa: E402  (reference)
+import nerf_to_coord as NC  # noqa: E402  (reference)
+from model import GaussNet as GN  # noqa: E402  (reference)
+
+torch.set_num_threads(8)
+T = torch.from_numpy
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print('%-28s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+def make_net(D, W, seed):
+    sd = synth.nerf_state_dict(D=D, W=W, seed=seed)
+    net = RH.NeRF(D=D, W=W, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    net.load_state_dict({k: T(v) for k, v in sd.items()})
+    return net
+
+
+class FixedRand:
+    """Replaces torch.rand inside the reference with a queue of known tensors ("identical seeds")."""
+
+    def __init__(self, tensors):
+        self.q = list(tensors)
+
+    def __call__(self, shape, *a, **k):
+        t = self.q.pop(0)
+        assert list(t.shape) == list(shape), (t.shape, shape)
+        return t
+
+
+# ---------------------------------------------------------------- G1 get_rays (RH:157-166)
+def g1():
+    out = {}
+    for H in (16, 800):
+        focal, K = synth.lego_intrinsics(H, H)
+        c2w = synth.pose_spherical(-117.0, -30.0, 4.0)[:3, :4]
+        with torch.no_grad():
+            ro, rd = RH.get_rays(H, H, K, T(c2w))
+        ro, rd = ro.numpy(), rd.numpy()
+        if H == 16:
+            out.update(K16=K, c2w16=c2w, rays_o16=ro, rays_d16=rd)
+        else:
+            rs = np.random.RandomState(1)
+            jj = np.concatenate([[0, 0, 799, 799, 400], rs.randint(0, 800, 251)])
+            ii = np.concatenate([[0, 799, 0, 799, 400], rs.randint(0, 800, 251)])
+            out.update(K800=K, c2w800=c2w, jj800=jj, ii800=ii, rays_o800=ro[jj, ii], rays_d800=rd[jj, ii])
+    save('g1_get_rays', **out)
+
+
+# ---------------------------------------------------------------- G2 Embedder (RH:15-67)
+def g2():
+    rs = np.random.RandomState(2)
+    pts = rs.uniform(-4, 4, size=(256, 3)).astype(np.float32)
+    dirs = rs.normal(size=(256, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    e10, d10 = RH.get_embedder(10, 0)
+    e4, d4 = RH.get_embedder(4, 0)
+    assert (d10, d4) == (63, 27)
+    save('g2_embed', pts=pts, dirs=dirs, emb_pts=e10(T(pts)).numpy(), emb_dirs=e4(T(dirs)).numpy())
+
+
+# ---------------------------------------------------------------- G3 NeRF.forward (RH:100-123)
+def g3():
+    rs = np.random.RandomState(3)
+    pts = rs.uniform(-1.5, 1.5, size=(512, 3)).astype(np.float32)
+    dirs = rs.normal(size=(512, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    e10, _ = RH.get_embedder(10, 0)
+    e4, _ = RH.get_embedder(4, 0)
+    emb = torch.cat([e10(T(pts)), e4(T(dirs))], -1)
+    out = dict(pts=pts, dirs=dirs)
+    for (D, W, seed) in ((8, 256, 10), (4, 64, 11)):
+        net = make_net(D, W, seed)
+        with torch.no_grad():
+            out['raw_D%dW%d' % (D, W)] = net(emb).numpy()
+        out['seed_D%dW%d' % (D, W)] = seed
+    # run_network (RN:37-51) with per-ray viewdirs expanded per sample
+    net = make_net(8, 256, 10)
+    with torch.no_grad():
+        raw = RN.run_network(T(pts).reshape(8, 64, 3), T(dirs[:8]), net, e10, e4, netchunk=1024 * 64)
+    out['run_network_raw'] = raw.numpy()
+    save('g3_nerf_forward', **out)
+
+
+# ---------------------------------------------------------------- G4 raw2outputs (RN:262-305)
+def g4():
+    out = {}
+    rs = np.random.RandomState(4)
+    for N in (64, 192):
+        R = 32
+        z = np.sort(rs.uniform(2, 6, size=(R, N)).astype(np.float32), -1)
+        rays_d = rs.normal(size=(R, 3)).astype(np.float32)
+        raw = rs.normal(size=(R, N, 4)).astype(np.float32)
+        raw[..., 3] *= 8.0
+        raw[0:4, :, 3] = -np.abs(raw[0:4, :, 3])           # all sigma <= 0 -> acc 0, disp NaN
+        raw[4:8, :, 3] = 50.0 + np.abs(raw[4:8, :, 3])      # saturated alpha = 1 at first sample
+        raw[8:10, N // 2:, 3] = 1e4                          # opaque wall half way
+        noise = rs.normal(size=(R, N)).astype(np.float32)
+        for wb in (False, True):
+            with torch.no_grad():
+                o = RN.raw2outputs(T(raw), T(z), T(rays_d), 0, wb)
+            tag = 'N%d_wb%d_' % (N, int(wb))
+            for k, v in zip(('rgb', 'disp', 'acc', 'weights', 'depth'), o):
+                out[tag + k] = v.numpy()
+        # raw_noise_std > 0 with an explicit noise tensor (torch.randn patched)
+        orig = torch.randn
+        torch.randn = FixedRand([T(noise)])
+        try:
+            with torch.no_grad():
+                o = RN.raw2outputs(T(raw), T(z), T(rays_d), 0.5, True)
+        finally:
+            torch.randn = orig
+        for k, v in zip(('rgb', 'disp', 'acc', 'weights', 'depth'), o):
+            out['N%d_noise_' % N + k] = v.numpy()
+        out.update({'N%d_raw' % N: raw, 'N%d_z' % N: z, 'N%d_rays_d' % N: rays_d, 'N%d_noise' % N: noise})
+    save('g4_raw2outputs', **out)
+
+
+# ---------------------------------------------------------------- G5 sample_pdf (RH:200-243)
+def g5():
+    rs = np.random.RandomState(5)
+    R = 48
+    z = np.sort(rs.uniform(2, 6, size=(R, 64)).astype(np.float32), -1)
+    bins = (.5 * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    w = rs.uniform(0, 1, size=(R, 62)).astype(np.float32) ** 4
+    w[0:4] = 0.0                          # all-zero weights -> uniform pdf from the 1e-5 floor
+    w[4:8] = 0.0
+    w[4:8, 17] = 1.0                      # single spike
+    w[8:12] = 1.0                         # exactly uniform
+    w[12:14, :30] = 0.0                   # long zero run then mass
+    u = rs.uniform(0, 1, size=(R, 128)).astype(np.float32)
+    u[:, 0] = 0.0
+    u[:, 1] = np.float32(1.0) - np.float32(2 ** -24)
+    with torch.no_grad():
+        det = RH.sample_pdf(T(bins), T(w), 128, det=True)
+        orig = torch.rand
+        torch.rand = FixedRand([T(u)])
+        try:
+            rnd = RH.sample_pdf(T(bins), T(w), 128, det=False)
+        finally:
+            torch.rand = orig
+        # merge + z_std exactly as RN:396, RN:412
+        zs, _ = torch.sort(torch.cat([T(z), rnd], -1), -1)
+        zstd = torch.std(rnd, dim=-1, unbiased=False)
+    save('g5_sample_pdf', z=z, bins=bins, weights=w, u=u, det=det.numpy(), rnd=rnd.numpy(),
+         merged=zs.numpy(), z_std=zstd.numpy())
+
+
+# ---------------------------------------------------------------- G6 render_rays / render end to end
+def g6():
+    out = {}
+    e10, _ = RH.get_embedder(10, 0)
+    e4, _ = RH.get_embedder(4, 0)
+
+    def query(inputs, viewdirs, network_fn):
+        return RN.run_network(inputs, viewdirs, network_fn, embed_fn=e10, embeddirs_fn=e4, netchunk=1024 * 64)
+
+    # cfg1: 64 coarse samples, D=4 W=64, no fine pass (BASELINE.json configs[0], R reduced to 64)
+    rays = synth.ray_batch(64, seed=60)
+    net = make_net(4, 64, 20)
+    with torch.no_grad():
+        r = RN.render_rays(T(rays), net, query, 64, retraw=True, white_bkgd=True)
+    out.update({'cfg1_' + k: v.numpy() for k, v in r.items()})
+    out['cfg1_rays'] = rays
+    out['cfg1_seed'] = 20
+
+    # cfg2 shape: 64+128, D=8 W=256, coarse+fine nets, from run_nerf.py AND nerf_to_coord.py (pts_max)
+    R = 32
+    rays = synth.ray_batch(R, seed=61)
+    coarse, fine = make_net(8, 256, 21), make_net(8, 256, 22)
+    out['cfg2_rays'] = rays
+    out['cfg2_seed_coarse'], out['cfg2_seed_fine'] = 21, 22
+    with torch.no_grad():
+        r = RN.render_rays(T(rays), coarse, query, 64, retraw=True, N_importance=128,
+                           network_fine=fine, white_bkgd=True)
+        rc = NC.render_rays(T(rays), coarse, query, 64, retraw=True, N_importance=128,
+                            network_fine=fine, white_bkgd=True)
+    for k in r:
+        assert torch.equal(r[k].nan_to_num(7.), rc[k].nan_to_num(7.)), k
+    out.update({'cfg2_det_' + k: v.numpy() for k, v in rc.items()})
+
+    # perturb = 1 with explicit t_rand / u ("identical seeds"): torch.rand patched in RN and RH
+    g = torch.Generator().manual_seed(0)
+    t_rand = torch.rand((R, 64), generator=g)
+    u = torch.rand((R, 128), generator=g)
+    orig = torch.rand
+    torch.rand = FixedRand([t_rand, u])
+    try:
+        with torch.no_grad():
+            rp = NC.render_rays(T(rays), coarse, query, 64, retraw=True, N_importance=128,
+                                network_fine=fine, white_bkgd=True, perturb=1.)
+    finally:
+        torch.rand = orig
+    out.update({'cfg2_pert_' + k: v.numpy() for k, v in rp.items()})
+    out['cfg2_t_rand'], out['cfg2_u'] = t_rand.numpy(), u.numpy()
+
+    # render() wrapper (RN:69-134 / NC:70-135) on a tiny full image from c2w
+    H = 8
+    focal, K = synth.lego_intrinsics(H, H)
+    c2w = synth.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    kw = dict(network_query_fn=query, perturb=0., N_importance=128, network_fine=fine, N_samples=64,
+              network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+    with torch.no_grad():
+        rgb, disp, acc, pts_max, extras = NC.render(H, H, K, chunk=40, c2w=T(c2w), near=2., far=6., **kw)
+    out.update(render_K=K, render_c2w=c2w, render_rgb=rgb.numpy(), render_disp=disp.numpy(),
+               render_acc=acc.numpy(), render_pts_max=pts_max.numpy(),
+               render_rgb0=extras['rgb0'].numpy(), render_z_std=extras['z_std'].numpy())
+    save('g6_render_rays', **out)
+
+
+# ---------------------------------------------------------------- G7 training-step gradients (RN:776-791)
+def g7():
+    e10, _ = RH.get_embedder(10, 0)
+    e4, _ = RH.get_embedder(4, 0)
+
+    def query(inputs, viewdirs, network_fn):
+        return RN.run_network(inputs, viewdirs, network_fn, embed_fn=e10, embeddirs_fn=e4, netchunk=1024 * 64)
+
+    out = {}
+    for tag, (D, W, R) in (('small', (4, 64, 32)), ('full', (8, 256, 16))):
+        rays = synth.ray_batch(R, seed=70)
+        coarse, fine = make_net(D, W, 31), make_net(D, W, 32)
+        g = torch.Generator().manual_seed(1)
+        t_rand = torch.rand((R, 64), generator=g)
+        u = torch.rand((R, 128), generator=g)
+        target = torch.rand((R, 3), generator=g)
+        orig = torch.rand
+        torch.rand = FixedRand([t_rand, u])
+        try:
+            r = RN.render_rays(T(rays), coarse, query, 64, retraw=True, N_importance=128,
+                               network_fine=fine, white_bkgd=True, perturb=1.)
+        finally:
+            torch.rand = orig
+        loss = RH.img2mse(r['rgb_map'], target) + RH.img2mse(r['rgb0'], target)
+        loss.backward()
+        out.update({tag + '_rays': rays, tag + '_t_rand': t_rand.numpy(), tag + '_u': u.numpy(),
+                    tag + '_target': target.numpy(), tag + '_loss': loss.item(),
+                    tag + '_rgb_map': r['rgb_map'].detach().numpy()})
+        for nm, net in (('coarse', coarse), ('fine', fine)):
+            for k, p in net.named_parameters():
+                gr = p.grad.numpy()
+                # store full small grads; for the big net keep norms + a slice to stay small
+                if tag == 'small':
+                    out['%s_%s_grad_%s' % (tag, nm, k)] = gr
+                else:
+                    out['%s_%s_gradnorm_%s' % (tag, nm, k)] = np.linalg.norm(gr.astype(np.float64))
+                    out['%s_%s_gradhead_%s' % (tag, nm, k)] = gr.reshape(-1)[:256]
+    save('g7_train_grads', **out)
+
+
+# ---------------------------------------------------------------- G8 8-NN (CI:126-145 re-issued)
+def ref_knn_procedure(Q, S, split_parts, top_number=8):
+    """The arithmetic lines of create_index_and_dist.py:126-145 around the same torch calls."""
+    chunks = S.chunk(split_parts, dim=0)
+    before = 0
+    idx_list, dist_list = [], []
+    for ch in chunks:
+        d = torch.cdist(Q, ch)
+        values, idx = torch.sort(d, dim=-1)
+        idx_list.append(idx[:, :, :top_number] + before)
+        dist_list.append(values[:, :, :top_number])
+        before += ch.size()[0]
+        it = torch.cat(idx_list, dim=-1)
+        dt = torch.cat(dist_list, dim=-1)
+        values, idx = torch.sort(dt, dim=-1)
+        idx_list = [it.gather(index=idx[:, :, :top_number], dim=-1)]
+        dist_list = [values[:, :, :top_number]]
+    return torch.cat([dist_list[0].unsqueeze(0), idx_list[0].unsqueeze(0)], dim=0)  # idx promoted to float
+
+
+def g8():
+    out = {}
+    # (a) small image-shaped case: Q 32x32, S = 3 views x 32x32
+    S = synth.sphere_shell_points(3 * 32 * 32, seed=80)
+    Q = synth.sphere_shell_points(32 * 32, seed=81).reshape(32, 32, 3)
+    Q[0, :8] = S[:8]                       # exact hits (distance 0)
+    S[100] = S[101]                        # duplicate points -> distance ties
+    out['a_S'], out['a_Q'] = S, Q
+    out['a_ref'] = ref_knn_procedure(T(Q), T(S), split_parts=4).numpy()
+    # (b) stress: 20k points, 24x24 queries, ragged chunking (20000 / 7)
+    S = synth.sphere_shell_points(20000, seed=82)
+    Q = synth.sphere_shell_points(24 * 24, seed=83).reshape(24, 24, 3)
+    out['b_S_seed'], out['b_Q_seed'] = 82, 83
+    out['b_ref'] = ref_knn_procedure(T(Q), T(S), split_parts=7).numpy()
+    # exact fp64 ground truth (index sets + distances) for both
+    for tag, (Qx, Sx) in (('a', (out['a_Q'], out['a_S'])), ('b', (Q, S))):
+        d = np.linalg.norm(Qx.reshape(-1, 1, 3).astype(np.float64) - Sx[None].astype(np.float64), axis=-1)
+        order = np.argsort(d, axis=-1, kind='stable')[:, :9]
+        out[tag + '_exact64_idx'] = order[:, :8].astype(np.int32)
+        out[tag + '_exact64_d9'] = np.take_along_axis(d, order, -1)
+    save('g8_knn', **out)
+
+
+# ---------------------------------------------------------------- G9 create_gauss_w (GN:169-186)
+def g9():
+    rs = np.random.RandomState(9)
+    B, H, W = 2, 16, 16
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    dist[0, 0, 0] = 5.0                   # all d >> c: sum g underflows to 0 -> w = 0 branch
+    dist[0, 0, 1] = 0.0                   # all exact hits
+    dist[0, 0, 2, 1:] = 9.0               # one neighbour only
+    idx = rs.randint(0, 3 * H * W, size=(B, H, W, 8)).astype(np.float32)
+    dai = np.stack([dist, idx], 1)
+    net = GN.create_gauss_w('cpu', 0.02)
+    with torch.no_grad():
+        i_w, d = net(T(dai))
+    save('g9_gauss_w', dist_and_index=dai, i_w=i_w.numpy(), dist=d.numpy())
+
+
+# ---------------------------------------------------------------- G10 gauss_net hot part (GN:46-119) + grads
+class _PoolCls(torch.nn.Module):
+    """Stand-in classifier (the real one is outside the hot path): 8 logits from pooled pixels."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.w = torch.nn.Parameter(torch.randn((8, 3 * 4 * 4), generator=g) * 0.01)
+
+    def forward(self, x):
+        p = torch.nn.functional.adaptive_avg_pool2d(x, 4).reshape(x.shape[0], -1)
+        return p @ self.w.t()
+
+
+def g10():
+    rs = np.random.RandomState(10)
+    P, B, H, W = 3, 2, 32, 32
+    s = rs.uniform(-40, 40, size=(P, H, W, 4)).astype(np.float32)
+    base_alpha = np.where(rs.uniform(size=(P, H, W)) < 0.8, 255.0, 0.0).astype(np.float32)
+    s[..., 3] = base_alpha
+    ori = synth.disc_alpha_image(B, H, W, seed=11)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, size=(B, H, W, 8)).astype(np.float32)
+    idx[0, 0, 0, :] = 7.0                 # one row gathered 8x by one pixel
+    idx[:, 5, :, 0] = 11.0                # a hot destination row (scatter-add contention)
+    with torch.no_grad():
+        wi, _ = GN.create_gauss_w('cpu', 0.02)(T(np.stack([dist, idx], 1)))
+    wi = wi.numpy()
+    Gx = rs.normal(size=(B, H, W, 4)).astype(np.float32)
+    Gr = rs.normal(size=(B, H, W, 4)).astype(np.float32)
+    out = dict(s=s, ori=ori, wi=wi, Gx=Gx, Gr=Gr)
+    for eps in (None, 32.0):
+        net = GN.gauss_net('cpu', 0.02, _PoolCls(), 'my_model', epsilon=eps)
+        st = T(s).clone().requires_grad_(True)
+        x, x_rgba, cla, ori_f, ori_cla = net(st, T(wi), T(ori))
+        # fixed upstream gradients Gx, Gr stand in for the classifier backward
+        (x * T(Gx)).sum().add((x_rgba * T(Gr)).sum()).backward()
+        tag = 'epsNone_' if eps is None else 'eps32_'
+        out.update({tag + 'x': x.detach().numpy(), tag + 'x_rgba': x_rgba.detach().numpy(),
+                    tag + 'grad_s': st.grad.numpy(),
+                    tag + 'eps3d_max': net.epsilon_3d_max, tag + 'eps3d_min': net.epsilon_3d_min})
+        # end-to-end through the stand-in classifier: CE loss -> grad wrt s
+        st2 = T(s).clone().requires_grad_(True)
+        _, _, cla, _, _ = net(st2, T(wi), T(ori))
+        loss = torch.nn.functional.cross_entropy(cla, torch.full((B,), 4, dtype=torch.long))
+        loss.backward()
+        out.update({tag + 'cla': cla.detach().numpy(), tag + 'ce_grad_s': st2.grad.numpy()})
+    out['cls_w'] = _PoolCls().w.detach().numpy()
+    save('g10_gauss_net', **out)
+
+
+# ---------------------------------------------------------------- G11 NeRFail-S sign step (AS:352-392 re-issued)
+def ref_igsm_step(s, grad, s_init, a, epsilon, targeted):
+    """Arithmetic of attack_NeRFail_S.py:352-392 (module-level script, cannot be imported)."""
+    alpha = s[:, :, :, 3].unsqueeze(-1).broadcast_to(s[:, :, :, :3].size())
+    rgba = s - a * torch.sign(grad) if targeted else s + a * torch.sign(grad)
+    rgb = torch.where(alpha > 0, rgba[:, :, :, :3], torch.zeros_like(rgba[:, :, :, :3]))
+    s = torch.cat([rgb, alpha[:, :, :, 0].unsqueeze(-1)], dim=-1)
+    mx = s_init[:, :, :, :3] + epsilon
+    mn = s_init[:, :, :, :3] - epsilon
+    temp = torch.cat([s[:, :, :, :3].unsqueeze(0), mn.unsqueeze(0)], 0)
+    s = torch.cat([torch.max(temp, dim=0)[0], s[:, :, :, 3].unsqueeze(-1)], dim=-1)
+    temp = torch.cat([s[:, :, :, :3].unsqueeze(0), mx.unsqueeze(0)], 0)
+    s = torch.cat([torch.min(temp, dim=0)[0], s[:, :, :, 3].unsqueeze(-1)], dim=-1)
+    return s
+
+
+def g11():
+    rs = np.random.RandomState(11)
+    P, H, W = 3, 16, 16
+    s_init = np.zeros((P, H, W, 4), np.float32)
+    s_init[..., 3] = np.where(rs.uniform(size=(P, H, W)) < 0.7, 255.0, 0.0)
+    s = s_init.copy()
+    s[..., :3] = rs.uniform(-34, 34, size=(P, H, W, 3)).astype(np.float32) * (s_init[..., 3:] > 0)
+    grad = rs.normal(size=(P, H, W, 4)).astype(np.float32)
+    grad[0, 0, :4] = 0.0                  # sign(0) = 0
+    out = dict(s=s, s_init=s_init, grad=grad)
+    for targeted in (False, True):
+        with torch.no_grad():
+            o = ref_igsm_step(T(s), T(grad), T(s_init), 2.0, 32.0, targeted)
+        out['out_targeted%d' % int(targeted)] = o.numpy()
+    save('g11_igsm_step', **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
+    for w in which:
+        globals()[w]()
