@@ -1,0 +1,174 @@
+/*
+ * nerfail_hip.h - C ABI of libnerfail_hip.so: the MI355X (gfx950) implementation of the NeRFail
+ * render-and-attack hot path.
+ *
+ * The reference (jiang-wenxiang/NeRFail) is pure Python/PyTorch and has no FFI of its own; its
+ * boundary is a set of Python call signatures. Each entry point below names the reference
+ * function (file:line, relative to the reference root) whose arithmetic it replaces; the Python
+ * mirror of those signatures lives in nerfail_amd/ and binds this library with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ *   RN = Create_spatial_point_set/nerf_pytorch/run_nerf.py      RH = .../run_nerf_helpers.py
+ *   NC = Create_spatial_point_set/nerf_to_coord.py              CI = .../create_index_and_dist.py
+ *   GN = model/GaussNet.py    AS = attack_NeRFail_S.py          DW = tools/dist_to_weight.py
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer to float32 unless the parameter name ends in `_host`.
+ *     Buffers are dense, row-major, 16-byte aligned (hipMalloc / torch allocations are).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Calls only enqueue
+ *     work; they never synchronise and never allocate.
+ *   - Inputs are borrowed and never written; outputs are fully overwritten unless stated.
+ *   - Return value: 0 on success, otherwise a NERFAIL_E* code; nerfail_last_error() then returns a
+ *     thread-local message (argument name or HIP error string).
+ *   - All arithmetic is IEEE float32 (the MLP uses the exact-f32 MFMA v_mfma_f32_32x32x2_f32).
+ */
+#ifndef NERFAIL_HIP_H
+#define NERFAIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERFAIL_ABI_VERSION 1
+
+#define NERFAIL_OK 0
+#define NERFAIL_EINVAL 1   /* bad argument (null pointer, size, unsupported shape) */
+#define NERFAIL_EHIP 2     /* a HIP runtime call or kernel launch failed           */
+#define NERFAIL_ENODEV 3   /* no gfx950 device visible                             */
+
+#define NERFAIL_RAY_FLOATS 11      /* o(3) d(3) near far viewdir(3): RN:116-123      */
+#define NERFAIL_KNN 8              /* top_number, CI:46                              */
+#define NERFAIL_MAX_DEPTH 16
+
+int nerfail_abi_version(void);
+const char* nerfail_last_error(void);
+/* name of the device the library will launch on ("gfx950..." expected); NERFAIL_ENODEV if none */
+int nerfail_device_name(char* buf_host, size_t buf_len);
+
+/* ------------------------------------------------------------------ rays (K1) ------------- */
+
+/* get_rays, RH:157-166. K4_host = {fx, fy, cx, cy} (K[0][0], K[1][1], K[0][2], K[1][2]),
+ * c2w_host = 12 floats, row-major [3,4]. Writes rays_o, rays_d as [H,W,3]. */
+int nerfail_get_rays(int H, int W, const float* K4_host, const float* c2w_host,
+                     float* rays_o, float* rays_d, void* stream);
+
+/* Ray packing of render(), RN:102-123 (use_viewdirs=True, ndc=False): viewdirs = d/|d|;
+ * rays[n, 11] = o, d, near, far, viewdirs. */
+int nerfail_pack_rays(const float* rays_o, const float* rays_d, int64_t n, float near_, float far_,
+                      float* rays, void* stream);
+
+/* get_rays + pack for the pixel range [pix_begin, pix_begin+pix_count) of an H x W image
+ * (row-major pixel index = row*W + col): the per-rank unit when a view is sharded. */
+int nerfail_ray_gen(int H, int W, const float* K4_host, const float* c2w_host, float near_, float far_,
+                    int64_t pix_begin, int64_t pix_count, float* rays, void* stream);
+
+/* ------------------------------------------------------------------ sampling (K2, K6) ----- */
+
+/* Coarse samples of render_rays, RN:357-381. t_vals[N] = torch.linspace(0,1,N) (host computes it so
+ * the bits are the reference's); t_rand[R,N] = stratified draws in [0,1) or NULL (perturb == 0).
+ * Writes z_vals[R,N] and pts[R,N,3] = o + d*z. */
+int nerfail_sample_coarse(const float* rays, int64_t n_rays, const float* t_vals, int n_samples,
+                          const float* t_rand, int lindisp, float* z_vals, float* pts, void* stream);
+
+/* sample_pdf, RH:200-243: bins[R,nb], weights[R,nb-1] -> samples[R,n]. u[R,n] explicit uniform draws
+ * (u_is_row != 0: one row u[n] shared by all rays, e.g. torch.linspace(0,1,n) for det=True). */
+int nerfail_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int n_bins,
+                       const float* u, int u_is_row, int n_samples, float* samples, void* stream);
+
+/* Hierarchical step of render_rays, RN:392-397 + RN:412, fused: z_mid, sample_pdf on weights[...,1:-1],
+ * sort(cat(z_vals, z_samples)), pts = o + d*z, z_std = std(z_samples, unbiased=False).
+ * z_coarse[R,Nc], weights[R,Nc] -> z_samples[R,Nf] (may be NULL), z_fine[R,Nc+Nf], pts[R,Nc+Nf,3], z_std[R]. */
+int nerfail_sample_fine(const float* rays, int64_t n_rays, const float* z_coarse, const float* weights,
+                        int n_coarse, const float* u, int u_is_row, int n_fine,
+                        float* z_samples, float* z_fine, float* pts, float* z_std, void* stream);
+
+/* ------------------------------------------------------------------ MLP (K3 + K4) --------- */
+
+/* Embedder.embed, RH:15-50 (log-sampled bands, include_input): x[M,3] -> out[M, 3 + 6*multires] =
+ * [x, sin(x*2^0), cos(x*2^0), ..., sin(x*2^(L-1)), cos(x*2^(L-1))]. Standalone form of the encoding;
+ * the render path never calls it (nerfail_mlp_fwd computes the encoding in registers). */
+int nerfail_embed(const float* x, int64_t M, int multires, float* out, void* stream);
+
+/* nn.Linear tensors of one NeRF (RH:83-98), weight layout [out, in] row-major as in the state_dict. */
+typedef struct nerfail_mlp_params {
+    int32_t D, W;                 /* netdepth, netwidth: (8,256) or (4,64); W % 32 == 0, W <= 256 */
+    int32_t input_ch;             /* 63 (multires 10)                                              */
+    int32_t input_ch_views;       /* 27 (multires_views 4)                                         */
+    int32_t skip;                 /* layer index after which [input_pts, h] is concatenated (4), -1 = none */
+    int32_t reserved;
+    const float* pts_w[NERFAIL_MAX_DEPTH];   /* pts_linears.i.weight */
+    const float* pts_b[NERFAIL_MAX_DEPTH];   /* pts_linears.i.bias   */
+    const float* views_w;  const float* views_b;      /* views_linears.0  [W/2, W+27] */
+    const float* feature_w; const float* feature_b;   /* feature_linear   [W, W]      */
+    const float* alpha_w;  const float* alpha_b;      /* alpha_linear     [1, W]      */
+    const float* rgb_w;    const float* rgb_b;        /* rgb_linear       [3, W/2]    */
+} nerfail_mlp_params;
+
+/* Number of floats of the MFMA-fragment-ordered weight image for a (D, W, skip) network; 0 if unsupported. */
+size_t nerfail_mlp_packed_floats(int D, int W, int skip);
+/* Re-pack the nn.Linear tensors into that image (device to device; call again after weights change). */
+int nerfail_mlp_pack(const nerfail_mlp_params* params_host, float* packed, void* stream);
+
+/* run_network, RN:37-51 (+ Embedder RH:15-50, NeRF.forward RH:100-123), fused: positional encoding of
+ * pts (L=10) and of the per-ray viewdir (L=4) is computed in registers and never written to memory.
+ * pts[M,3]; viewdirs[n_rays,3] with sample m using row m / samples_per_ray; raw[M,4] = rgb(3), sigma(1). */
+int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, const float* pts, const float* viewdirs,
+                    int64_t M, int samples_per_ray, float* raw, void* stream);
+
+/* NeRF.forward on an already embedded batch x[M, 63+27] (RH:100-123 as a standalone call). */
+int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int skip, const float* x, int64_t M,
+                             float* raw, void* stream);
+
+/* ------------------------------------------------------------------ compositing (K5, K7) -- */
+
+/* raw2outputs, RN:262-305, one wavefront per ray with a wave-level exclusive product scan.
+ * raw[R,N,4], z_vals[R,N], rays (packed [R,11]; d is read from it), noise[R,N] already scaled by
+ * raw_noise_std or NULL. Outputs rgb_map[R,3], disp_map[R], acc_map[R], weights[R,N], depth_map[R];
+ * if pts[R,N,3] and pts_max[R,3] are non-NULL also NC:418-423 (first argmax of weights -> point). */
+int nerfail_composite(const float* raw, const float* z_vals, const float* rays, const float* noise,
+                      int64_t n_rays, int n_samples, int white_bkgd,
+                      float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
+                      const float* pts, float* pts_max, void* stream);
+
+/* ------------------------------------------------------------------ 8-NN build (K8) ------- */
+
+/* create_index_and_dist core, CI:126-145, exact: for each query the 8 smallest keys
+ * (d2, index) with d2 = ((dx*dx + dy*dy) + dz*dz) in float32 without FMA; dist = sqrt(d2).
+ * queries[Nq,3], points[M,3] (M < 2^24 so indices are exact in float32, as on disk CI:148-163).
+ * dist[Nq,8] ascending; idx_f32[Nq,8] (may be NULL) and idx_i32[Nq,8] (may be NULL). */
+int nerfail_knn8(const float* queries, int64_t n_queries, const float* points, int64_t n_points,
+                 float* dist, float* idx_f32, int32_t* idx_i32, void* stream);
+
+/* ------------------------------------------------------------------ gauss path (K9-K12) --- */
+
+/* create_gauss_w.forward, GN:169-186 (driver DW:82-97): dist_and_index[B,2,P,8] -> out[B,2,P,8]
+ * (weight, index) with g = exp(-(d/c)^2/2), w = g/(sum g + 0.001) if sum g > 0 else 0. P = H*W. */
+int nerfail_gauss_weight(const float* dist_and_index, int64_t B, int64_t P, float c, float* out, void* stream);
+
+/* gauss_net.forward hot part, GN:53-119. spatial[Ns,4] (BGRA, 0..255), weight_and_index[B,2,P,8],
+ * ori_img[B,P,4] float. epsilon < 0 means None (no clip). Writes x[B,P,4], x_rgba[B,P,4];
+ * eps_minmax (2 floats, may be NULL) is UPDATED with the running min / max of x_rgb*alpha (GN:89-103):
+ * eps_minmax[0] = min(old, new_min), eps_minmax[1] = max(old, new_max). */
+int nerfail_gauss_fwd(const float* spatial, int64_t Ns, const float* weight_and_index, const float* ori_img,
+                      int64_t B, int64_t P, float epsilon, float* x, float* x_rgba, float* eps_minmax,
+                      void* stream);
+
+/* Backward of the above (autograd of GN:63-119): grad_spatial[Ns,4] += d/ds( sum(x*grad_x) +
+ * sum(x_rgba*grad_x_rgba) ). grad_x / grad_x_rgba may be NULL (treated as zero). x is the forward's
+ * saved output. grad_spatial is ACCUMULATED into (zero it first for a fresh gradient) with float atomics. */
+int nerfail_gauss_bwd(const float* weight_and_index, const float* ori_img, const float* x,
+                      const float* grad_x, const float* grad_x_rgba, int64_t Ns, int64_t B, int64_t P,
+                      float epsilon, float* grad_spatial, void* stream);
+
+/* NeRFail-S sign step, AS:352-392: rgb <- rgb -/+ a*sign(grad) where alpha > 0 else 0, clamped to
+ * init +- epsilon; alpha channel copied. spatial/grad/spatial_init/out are [n,4]; out may alias spatial. */
+int nerfail_igsm_step(const float* spatial, const float* grad, const float* spatial_init, int64_t n,
+                      float a, float epsilon, int targeted, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFAIL_HIP_H */

@@ -1,0 +1,62 @@
+"""The attack-step arithmetic of attack_NeRFail_S.py (reference = AS), on the MI355X.
+
+`igsm_step` is AS:352-392 as one kernel. `nerfail_s_step` is one iteration of the AS:304-392 loop body
+(forward through gauss_net, CE loss, backward to the perturbation, sign step, epsilon clamp); with
+torch.distributed initialised it shards the batch's views over ranks and sums the perturbation gradient
+with ONE all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests) before every rank applies the
+identical step - the only collective on the whole path.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from . import sharding
+from .run_nerf_helpers import _cuda
+
+
+def igsm_step(spatial, grad, spatial_init, a=2.0, epsilon=32.0, targeted=False, out=None):
+    """AS:352-392: rgb <- rgb -/+ a*sign(grad) where alpha > 0 else 0; clamp to init +- epsilon; alpha kept."""
+    dev = _cuda()
+    s = _lib.f32c(spatial, dev)
+    g = _lib.f32c(grad, dev)
+    s0 = _lib.f32c(spatial_init, dev)
+    if s.shape[-1] != 4 or g.shape != s.shape or s0.shape != s.shape:
+        raise ValueError('spatial, grad and spatial_init must all be [..., 4] of the same shape')
+    if out is None:
+        out = torch.empty_like(s)
+    n = s.numel() // 4
+    _lib.check(_lib.load().nerfail_igsm_step(_lib.dev(s), _lib.dev(g), _lib.dev(s0), n, float(a), float(epsilon),
+                                             int(bool(targeted)), _lib.dev(out), _lib.stream()))
+    return out
+
+
+def perturbation_grad(net, spatial, weight_and_index, ori_img, label, batch_total=None, grad_fn=None):
+    """d(CE(cla, label))/d(spatial) for the views given (AS:317-348). `batch_total` = views in the WHOLE batch
+    (CE is a mean over the batch, so a shard holding k of B views contributes with weight k/B)."""
+    s = spatial.detach().clone().requires_grad_(True)
+    x, r, cla, ori, ori_cla = net(s, weight_and_index, ori_img)
+    lab = label.to(cla.device).broadcast_to([cla.shape[0]])
+    if grad_fn is not None:
+        loss = grad_fn(cla, lab)
+    else:
+        loss = torch.nn.functional.cross_entropy(cla, lab, reduction='sum') / float(batch_total or cla.shape[0])
+    loss.backward()
+    return s.grad, loss.detach(), cla.detach()
+
+
+def nerfail_s_step(net, spatial, spatial_init, weight_and_index, ori_img, label, a=2.0, epsilon=32.0,
+                   targeted=False, group=None):
+    """One NeRFail-S iteration on one batch of views. Sharded over ranks when torch.distributed is up."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    B = weight_and_index.shape[0]
+    lo, hi = sharding.shard_range(B, rank, world)
+    if hi > lo:
+        g, loss, _ = perturbation_grad(net, spatial, weight_and_index[lo:hi], ori_img[lo:hi], label, batch_total=B)
+    else:
+        g = torch.zeros_like(spatial)
+        loss = torch.zeros((), device=spatial.device)
+    if world > 1:
+        sharding.all_reduce_sum_(g, group)           # C1: the perturbation-gradient all-reduce
+        sharding.all_reduce_sum_(loss, group)
+    return igsm_step(spatial, g, spatial_init, a, epsilon, targeted), loss

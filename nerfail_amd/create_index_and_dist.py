@@ -1,0 +1,57 @@
+"""MI355X mirror of Create_spatial_point_set/create_index_and_dist.py (reference = CI).
+
+`index_and_dist(view_pts, point_set)` is the arithmetic core (CI:126-145) as one exact streaming kernel;
+`create_index_and_dist(label, epochs, mask_list)` keeps the file-level contract (CI:22-170): reads the
+pts_max .npy files nerf_to_coord wrote, writes index_and_dist/<split>/<i>.pth, float32 [2,H,W,8] =
+(distance ascending, global index stored as float).
+
+Ordering is exact (direct-difference float32 d2, ties by index) where the reference's torch.cdist
+matmul path is noisy; see oracle/knn.py for the definition and tests/test_oracle_knn.py for how the two
+relate.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .run_nerf_helpers import _cuda
+
+
+def knn8(queries, points, want_int=False):
+    """queries [...,3], points [M,3] -> (dist [...,8] ascending, idx [...,8] float32 | int32)."""
+    dev = _cuda()
+    q = _lib.f32c(queries, dev)
+    p = _lib.f32c(points, dev).reshape(-1, 3)
+    lead = q.shape[:-1]
+    q2 = q.reshape(-1, 3)
+    dist = torch.empty((q2.shape[0], 8), dtype=torch.float32, device=dev)
+    idx = torch.empty((q2.shape[0], 8), dtype=torch.int32 if want_int else torch.float32, device=dev)
+    _lib.check(_lib.load().nerfail_knn8(_lib.dev(q2, 'queries'), q2.shape[0], _lib.dev(p, 'points'), p.shape[0],
+                                        _lib.dev(dist), None if want_int else _lib.dev(idx),
+                                        _lib.dev(idx) if want_int else None, _lib.stream()))
+    return dist.reshape(tuple(lead) + (8,)), idx.reshape(tuple(lead) + (8,))
+
+
+def index_and_dist(view_pts, point_set):
+    """One view: pts_max [H,W,3] vs point set [M,3] -> float32 [2,H,W,8] exactly as saved at CI:148-163."""
+    d, i = knn8(view_pts, point_set)
+    return torch.stack([d, i], 0)
+
+
+def create_index_and_dist(label, epochs, mask_list, basedir='.', train_img_num=100, val_img_num=100,
+                          test_img_num=200):
+    """CI:22-170 file contract (paths relative to `basedir`, default the current directory as in the reference)."""
+    log_data_dir = os.path.join(basedir, 'logs', 'blender_paper_' + label)
+    coord_dir = {s: os.path.join(log_data_dir, 'renderonly_%s_%s' % (s, epochs)) for s in ('test', 'train', 'val')}
+    save_dir = {s: os.path.join(log_data_dir, 'index_and_dist', s) for s in ('test', 'train', 'val')}
+    dev = _cuda()
+    base = [torch.from_numpy(np.load(os.path.join(coord_dir['test'], '%03d.npy' % i))).to(dev) for i in mask_list]
+    point_set = torch.reshape(torch.stack(base), (-1, 3))                              # CI:57-61
+    for tab, n in (('test', test_img_num), ('train', train_img_num), ('val', val_img_num)):   # CI:110
+        os.makedirs(save_dir[tab], exist_ok=True)
+        for img_i in range(n):
+            pts = torch.from_numpy(np.load(os.path.join(coord_dir[tab], '%03d.npy' % img_i))).to(dev)
+            out = index_and_dist(pts, point_set)
+            torch.save(out.cpu(), os.path.join(save_dir[tab], str(img_i) + '.pth'))
+            print(tab + ' [' + str(img_i + 1) + '/' + str(n) + ']')

@@ -1,0 +1,72 @@
+// Shared helpers for libnerfail_hip.so (gfx950 only). Error reporting follows include/nerfail_hip.h:
+// every entry point returns 0 or a NERFAIL_E* code and leaves a thread-local message behind.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/nerfail_hip.h"
+
+namespace nerfail {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define NF_REQUIRE(cond, msg)                                   \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            ::nerfail::set_error("%s: %s", __func__, msg);      \
+            return NERFAIL_EINVAL;                              \
+        }                                                       \
+    } while (0)
+
+// After a <<<>>> launch: surface launch-configuration errors as NERFAIL_EHIP.
+#define NF_LAUNCHED(name)                                       \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return ::nerfail::hip_fail(e__, name); \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;
+
+// ---- wave-level primitives (64 lanes) -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// inclusive product scan across the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_scan_add_f64(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// pts = o + d*z with the reference's rounding (multiply, then add; no FMA): RN:381
+__device__ __forceinline__ float mul_add_rn(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }
+
+}  // namespace nerfail

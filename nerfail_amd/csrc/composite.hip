@@ -1,0 +1,138 @@
+// K5 alpha compositing (+ K7 pts_max epilogue): raw2outputs, run_nerf.py:262-305, and the
+// argmax-weight point of nerf_to_coord.py:418-423.
+//
+// One wavefront per ray. Lane l owns IPL consecutive samples (IPL = ceil(N/64): 1 for the 64 coarse
+// samples, 3 for the 192 fine ones), so every global access is a contiguous run per lane and a
+// contiguous span per wave. The exclusive transmittance cumprod is a lane-local product followed by a
+// 64-lane shuffle scan; the ray sums are shuffle reductions. No LDS.
+//
+// HBM-bound: algorithmic bytes per ray = 24*N + 36 (+12*N+12 when pts_max is requested: it reads one
+// point per ray, 12 B, the figure quoted in DESIGN.md uses the raw2outputs form).
+#include "common.h"
+
+namespace nerfail {
+
+template <int IPL>
+__global__ __launch_bounds__(256) void composite_kernel(
+    const float4* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays,
+    const float* __restrict__ noise, long n_rays, int N, int white_bkgd,
+    float* __restrict__ rgb_map, float* __restrict__ disp_map, float* __restrict__ acc_map,
+    float* __restrict__ weights, float* __restrict__ depth_map,
+    const float* __restrict__ pts, float* __restrict__ pts_max) {
+    const int lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;   // whole wave exits together
+
+    const float* rr = rays + NERFAIL_RAY_FLOATS * ray;
+    const float dx = rr[3], dy = rr[4], dz = rr[5];
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+
+    const long base = ray * N;
+    const int i0 = lane * IPL;
+
+    float z[IPL + 1];
+    float alpha[IPL], rgbr[IPL], rgbg[IPL], rgbb[IPL];
+#pragma unroll
+    for (int k = 0; k <= IPL; ++k) {
+        const int i = i0 + k;
+        z[k] = (i < N) ? z_vals[base + i] : 0.0f;
+    }
+    float tprod = 1.0f;          // product of this lane's (1-alpha+1e-10)
+#pragma unroll
+    for (int k = 0; k < IPL; ++k) {
+        const int i = i0 + k;
+        alpha[k] = 0.0f; rgbr[k] = rgbg[k] = rgbb[k] = 0.0f;
+        if (i < N) {
+            const float4 rw = raw[base + i];
+            float dist = (i < N - 1) ? __fsub_rn(z[k + 1], z[k]) : 1e10f;
+            dist = __fmul_rn(dist, nrm);
+            float sigma = rw.w;
+            if (noise != nullptr) sigma = __fadd_rn(sigma, noise[base + i]);
+            sigma = fmaxf(sigma, 0.0f);
+            alpha[k] = __fsub_rn(1.0f, expf(-__fmul_rn(sigma, dist)));
+            rgbr[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.x)));
+            rgbg[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.y)));
+            rgbb[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.z)));
+            tprod = __fmul_rn(tprod, __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f));
+        }
+    }
+    // exclusive scan of lane products -> transmittance in front of this lane's first sample
+    const float incl = wave_scan_mul(tprod, lane);
+    float T = __shfl_up(incl, 1, 64);
+    if (lane == 0) T = 1.0f;
+
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    float best_w = -1.0f;
+    int best_i = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < IPL; ++k) {
+        const int i = i0 + k;
+        if (i < N) {
+            const float w = __fmul_rn(alpha[k], T);
+            if (weights != nullptr) weights[base + i] = w;
+            sr += w * rgbr[k]; sg += w * rgbg[k]; sb += w * rgbb[k];
+            sd += w * z[k];
+            sa += w;
+            if (w > best_w) { best_w = w; best_i = i; }          // first maximum inside the lane
+            T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f));
+        }
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+
+    if (pts_max != nullptr) {   // torch.argmax returns the FIRST maximal index (NC:418)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ow = __shfl_xor(best_w, o, 64);
+            const int oi = __shfl_xor(best_i, o, 64);
+            if (ow > best_w || (ow == best_w && oi < best_i)) { best_w = ow; best_i = oi; }
+        }
+        if (best_i >= N) best_i = 0;   // all-NaN weights: never index outside the ray
+        if (lane < 3) pts_max[3 * ray + lane] = pts[3 * (base + best_i) + lane];
+    }
+
+    if (lane == 0) {
+        const float ratio = __fdiv_rn(sd, sa);
+        // torch.max(1e-10, ratio) propagates NaN (acc == 0 -> 0/0): RN:299
+        const float disp = (ratio != ratio) ? ratio : __fdiv_rn(1.0f, fmaxf(1e-10f, ratio));
+        if (white_bkgd) {
+            const float bg = __fsub_rn(1.0f, sa);
+            sr += bg; sg += bg; sb += bg;
+        }
+        rgb_map[3 * ray + 0] = sr; rgb_map[3 * ray + 1] = sg; rgb_map[3 * ray + 2] = sb;
+        disp_map[ray] = disp;
+        acc_map[ray] = sa;
+        if (depth_map != nullptr) depth_map[ray] = sd;
+    }
+}
+
+}  // namespace nerfail
+
+using namespace nerfail;
+
+extern "C" int nerfail_composite(const float* raw, const float* z_vals, const float* rays, const float* noise,
+                                 int64_t n_rays, int n_samples, int white_bkgd, float* rgb_map, float* disp_map,
+                                 float* acc_map, float* weights, float* depth_map, const float* pts, float* pts_max,
+                                 void* stream) {
+    NF_REQUIRE(n_rays >= 0, "n_rays is negative");
+    NF_REQUIRE(n_samples >= 1 && n_samples <= 256, "n_samples must be in [1, 256]");
+    if (n_rays == 0) return NERFAIL_OK;
+    NF_REQUIRE(raw != nullptr && z_vals != nullptr && rays != nullptr, "raw / z_vals / rays is NULL");
+    NF_REQUIRE(rgb_map != nullptr && disp_map != nullptr && acc_map != nullptr, "rgb_map / disp_map / acc_map is NULL");
+    NF_REQUIRE((pts == nullptr) == (pts_max == nullptr), "pts and pts_max must be given together");
+    const dim3 block(256), grid((unsigned)((n_rays + 3) / 4));
+    const int ipl = (n_samples + 63) / 64;
+    hipStream_t s = as_stream(stream);
+#define NF_COMPOSITE(IPL)                                                                                     \
+    composite_kernel<IPL><<<grid, block, 0, s>>>((const float4*)raw, z_vals, rays, noise, n_rays, n_samples,   \
+                                                 white_bkgd, rgb_map, disp_map, acc_map, weights, depth_map,   \
+                                                 pts, pts_max)
+    switch (ipl) {
+        case 1: NF_COMPOSITE(1); break;
+        case 2: NF_COMPOSITE(2); break;
+        case 3: NF_COMPOSITE(3); break;
+        default: NF_COMPOSITE(4); break;
+    }
+#undef NF_COMPOSITE
+    NF_LAUNCHED("composite_kernel");
+    return NERFAIL_OK;
+}

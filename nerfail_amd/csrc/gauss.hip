@@ -1,0 +1,242 @@
+// K9-K12: the differentiable pixel <-> 3-D-point map of the NeRFail attacks.
+//   K9  gauss_weight   create_gauss_w.forward           model/GaussNet.py:169-186
+//   K10 gauss_fwd      gauss_net.forward (hot part)      model/GaussNet.py:53-119
+//   K11 gauss_bwd      autograd of the above             (gather backward = scatter-add)
+//   K12 igsm_step      NeRFail-S sign step               attack_NeRFail_S.py:352-392
+//
+// All four are HBM-bound streaming kernels over pixels (one thread per pixel, 32 B of weights + 32 B of
+// indices per pixel read as two float4 pairs); K10 adds 8 random 16-B row gathers from the 30.7 MB
+// perturbation table (Infinity-Cache resident), K11 8 x 4 float atomics per pixel into it.
+#include "common.h"
+
+namespace nerfail {
+
+// ------------------------------------------------------------------------------------------ K9
+__global__ __launch_bounds__(256) void gauss_weight_kernel(const float* __restrict__ dai, long B, long P, float c,
+                                                           float* __restrict__ out) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B * P) return;
+    const long b = g / P, p = g - b * P;
+    const float4* dist4 = reinterpret_cast<const float4*>(dai + ((b * 2 + 0) * P + p) * 8);
+    const float4* idx4 = reinterpret_cast<const float4*>(dai + ((b * 2 + 1) * P + p) * 8);
+    float4* w4 = reinterpret_cast<float4*>(out + ((b * 2 + 0) * P + p) * 8);
+    float4* i4 = reinterpret_cast<float4*>(out + ((b * 2 + 1) * P + p) * 8);
+    const float4 da = dist4[0], db = dist4[1];
+    const float d[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+    float gk[8];
+    float ds = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float q = __fdiv_rn(d[k], c);
+        gk[k] = expf(-__fdiv_rn(__fmul_rn(q, q), 2.0f));     // exp(-(d/c)^2 / 2)
+        ds = __fadd_rn(ds, gk[k]);
+    }
+    const float dq = __fadd_rn(ds, 0.001f);
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = (ds > 0.f) ? __fdiv_rn(gk[k], dq) : 0.f;
+    w4[0] = make_float4(w[0], w[1], w[2], w[3]);
+    w4[1] = make_float4(w[4], w[5], w[6], w[7]);
+    i4[0] = idx4[0];
+    i4[1] = idx4[1];
+}
+
+// ------------------------------------------------------------------------------------------ K10
+// block-level min/max of x_rgb*alpha folded into eps_minmax with float atomics (ordered-int trick
+// is unnecessary: atomicMin/atomicMax on float exist for HIP via CAS-free int reinterpretation only
+// for non-negative values, so use the sign-aware integer form).
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+    if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict__ spatial, long Ns,
+                                                        const float* __restrict__ wi, const float4* __restrict__ ori,
+                                                        long B, long P, float epsilon, float4* __restrict__ x_out,
+                                                        float4* __restrict__ x_rgba, float* __restrict__ eps_minmax) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float emin = 0.f, emax = 0.f;   // the running values start at 0 (GN:27-28), so 0 is neutral
+    if (g < B * P) {
+        const long b = g / P, p = g - b * P;
+        const float4* w4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 0) * P + p) * 8);
+        const float4* i4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 1) * P + p) * 8);
+        const float4 wa = w4[0], wb = w4[1], ia = i4[0], ib = i4[1];
+        const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        const float fi[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        float4 rows[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {     // issue all 8 gathers before using any
+            long j = (long)fi[k];         // .type(torch.long): truncation (GN:62)
+            j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
+            rows[k] = spatial[j];
+        }
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {     // x = sum_k s[idx_k] * w_k, sequential in k (GN:81-83)
+            x.x = __fadd_rn(x.x, __fmul_rn(rows[k].x, w[k]));
+            x.y = __fadd_rn(x.y, __fmul_rn(rows[k].y, w[k]));
+            x.z = __fadd_rn(x.z, __fmul_rn(rows[k].z, w[k]));
+            x.w = __fadd_rn(x.w, __fmul_rn(rows[k].w, w[k]));
+        }
+        const float alpha = __fdiv_rn(x.w, 255.0f);
+        const float4 o = ori[g];
+        float dlt[3] = {__fmul_rn(x.x, alpha), __fmul_rn(x.y, alpha), __fmul_rn(x.z, alpha)};
+        if (alpha > 0.f) {                // GN:89-103 bookkeeping uses where(alpha>0, x, 0) * alpha
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { emin = fminf(emin, dlt[c]); emax = fmaxf(emax, dlt[c]); }
+        }
+        float rgb[3];
+        const float oc[3] = {o.x, o.y, o.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = dlt[c];
+            if (epsilon >= 0.f) d = fminf(fmaxf(d, -epsilon), epsilon);
+            float v = (o.w > 0.f) ? __fadd_rn(oc[c], d) : 0.f;
+            rgb[c] = fminf(fmaxf(v, 0.f), 255.f);
+        }
+        x_out[g] = x;
+        x_rgba[g] = make_float4(rgb[0], rgb[1], rgb[2], fminf(fmaxf(o.w, 0.f), 255.f));
+    }
+    if (eps_minmax != nullptr) {
+        emin = wave_min(emin);
+        emax = wave_max(emax);
+        if ((threadIdx.x & 63) == 0) {
+            if (emin < 0.f) atomic_min_f32(eps_minmax + 0, emin);
+            if (emax > 0.f) atomic_max_f32(eps_minmax + 1, emax);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K11
+__global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* __restrict__ wi, const float4* __restrict__ ori,
+                                                        const float4* __restrict__ x_saved,
+                                                        const float4* __restrict__ grad_x,
+                                                        const float4* __restrict__ grad_x_rgba, long Ns, long B, long P,
+                                                        float epsilon, float* __restrict__ grad_spatial) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B * P) return;
+    const long b = g / P, p = g - b * P;
+    const float4 x = x_saved[g];
+    const float4 o = ori[g];
+    float4 gx = (grad_x != nullptr) ? grad_x[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grad_x_rgba != nullptr && o.w > 0.f) {
+        const float4 gr = grad_x_rgba[g];
+        const float alpha = x.w / 255.0f;
+        const float xc[3] = {x.x, x.y, x.z}, oc[3] = {o.x, o.y, o.z}, grc[3] = {gr.x, gr.y, gr.z};
+        float gxc[3] = {0.f, 0.f, 0.f};
+        float ga = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = xc[c] * alpha;
+            bool pass = true;
+            if (epsilon >= 0.f) {         // clip backward passes inside [min, max] inclusive
+                pass = (d >= -epsilon) && (d <= epsilon);
+                d = fminf(fmaxf(d, -epsilon), epsilon);
+            }
+            const float pre = oc[c] + d;
+            pass = pass && (pre >= 0.f) && (pre <= 255.f);
+            const float gd = pass ? grc[c] : 0.f;
+            gxc[c] = gd * alpha;
+            ga += gd * xc[c];
+        }
+        gx.x += gxc[0]; gx.y += gxc[1]; gx.z += gxc[2];
+        gx.w += ga / 255.0f;
+    }
+    if (gx.x == 0.f && gx.y == 0.f && gx.z == 0.f && gx.w == 0.f) return;   // background pixels: nothing to scatter
+    const float4* w4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 0) * P + p) * 8);
+    const float4* i4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 1) * P + p) * 8);
+    const float4 wa = w4[0], wb = w4[1], ia = i4[0], ib = i4[1];
+    const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    const float fi[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (w[k] == 0.f) continue;
+        long j = (long)fi[k];
+        j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
+        float* dst = grad_spatial + 4 * j;
+        atomicAdd(dst + 0, w[k] * gx.x);
+        atomicAdd(dst + 1, w[k] * gx.y);
+        atomicAdd(dst + 2, w[k] * gx.z);
+        atomicAdd(dst + 3, w[k] * gx.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K12
+__global__ __launch_bounds__(256) void igsm_step_kernel(const float4* __restrict__ s, const float4* __restrict__ grad,
+                                                        const float4* __restrict__ s_init, long n, float a, float epsilon,
+                                                        int targeted, float4* __restrict__ out) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const float4 v = s[g], gr = grad[g], in = s_init[g];
+    const float sv[3] = {v.x, v.y, v.z}, gv[3] = {gr.x, gr.y, gr.z}, iv[3] = {in.x, in.y, in.z};
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float sg = (gv[c] > 0.f) ? 1.f : ((gv[c] < 0.f) ? -1.f : 0.f);   // torch.sign (sign(0) = 0)
+        const float st = __fmul_rn(a, sg);
+        float q = targeted ? __fsub_rn(sv[c], st) : __fadd_rn(sv[c], st);
+        q = (v.w > 0.f) ? q : 0.f;
+        q = fmaxf(q, __fsub_rn(iv[c], epsilon));
+        q = fminf(q, __fadd_rn(iv[c], epsilon));
+        r[c] = q;
+    }
+    out[g] = make_float4(r[0], r[1], r[2], v.w);
+}
+
+}  // namespace nerfail
+
+using namespace nerfail;
+
+extern "C" int nerfail_gauss_weight(const float* dist_and_index, int64_t B, int64_t P, float c, float* out, void* stream) {
+    NF_REQUIRE(B >= 0 && P >= 0, "negative size");
+    NF_REQUIRE(c > 0.f, "c must be positive");
+    if (B * P == 0) return NERFAIL_OK;
+    NF_REQUIRE(dist_and_index != nullptr && out != nullptr, "NULL pointer");
+    gauss_weight_kernel<<<dim3((unsigned)((B * P + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(dist_and_index, B, P, c, out);
+    NF_LAUNCHED("gauss_weight_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_gauss_fwd(const float* spatial, int64_t Ns, const float* weight_and_index, const float* ori_img,
+                                 int64_t B, int64_t P, float epsilon, float* x, float* x_rgba, float* eps_minmax,
+                                 void* stream) {
+    NF_REQUIRE(Ns > 0 && B >= 0 && P >= 0, "bad sizes");
+    if (B * P == 0) return NERFAIL_OK;
+    NF_REQUIRE(spatial != nullptr && weight_and_index != nullptr && ori_img != nullptr, "NULL input pointer");
+    NF_REQUIRE(x != nullptr && x_rgba != nullptr, "NULL output pointer");
+    gauss_fwd_kernel<<<dim3((unsigned)((B * P + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        (const float4*)spatial, Ns, weight_and_index, (const float4*)ori_img, B, P, epsilon, (float4*)x, (float4*)x_rgba,
+        eps_minmax);
+    NF_LAUNCHED("gauss_fwd_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_gauss_bwd(const float* weight_and_index, const float* ori_img, const float* x, const float* grad_x,
+                                 const float* grad_x_rgba, int64_t Ns, int64_t B, int64_t P, float epsilon,
+                                 float* grad_spatial, void* stream) {
+    NF_REQUIRE(Ns > 0 && B >= 0 && P >= 0, "bad sizes");
+    if (B * P == 0) return NERFAIL_OK;
+    NF_REQUIRE(weight_and_index != nullptr && ori_img != nullptr && x != nullptr, "NULL input pointer");
+    NF_REQUIRE(grad_spatial != nullptr, "grad_spatial is NULL");
+    if (grad_x == nullptr && grad_x_rgba == nullptr) return NERFAIL_OK;
+    gauss_bwd_kernel<<<dim3((unsigned)((B * P + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        weight_and_index, (const float4*)ori_img, (const float4*)x, (const float4*)grad_x, (const float4*)grad_x_rgba, Ns,
+        B, P, epsilon, grad_spatial);
+    NF_LAUNCHED("gauss_bwd_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_igsm_step(const float* spatial, const float* grad, const float* spatial_init, int64_t n, float a,
+                                 float epsilon, int targeted, float* out, void* stream) {
+    NF_REQUIRE(n >= 0, "n is negative");
+    if (n == 0) return NERFAIL_OK;
+    NF_REQUIRE(spatial != nullptr && grad != nullptr && spatial_init != nullptr && out != nullptr, "NULL pointer");
+    igsm_step_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        (const float4*)spatial, (const float4*)grad, (const float4*)spatial_init, n, a, epsilon, targeted, (float4*)out);
+    NF_LAUNCHED("igsm_step_kernel");
+    return NERFAIL_OK;
+}

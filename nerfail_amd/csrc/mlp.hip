@@ -1,0 +1,413 @@
+// K3 + K4: fused positional encoding + NeRF MLP forward on the exact-f32 matrix cores.
+// Replaces run_network (run_nerf.py:37-51), Embedder.embed (run_nerf_helpers.py:15-50) and
+// NeRF.forward (run_nerf_helpers.py:100-123); ~99 % of the render path's FLOPs.
+//
+// Design (CDNA4 / gfx950, wave64, v_mfma_f32_32x32x2_f32 = bit-exact f32 FMA chain):
+//   * Every layer is computed TRANSPOSED: H^T[out, sample] = W[out, in] * X^T[in, sample]. The MFMA
+//     A operand is a 32-row slab of W, the B operand is the activation, so the 32x32 accumulator
+//     tile holds "sample on the lane, output channel on the register": lane l (h = l>>5, j = l&31)
+//     owns sample j and channels c(r,h) = (r&3) + 8*(r>>2) + 4*h of the tile in registers r=0..15.
+//   * That is exactly the B-operand shape of the NEXT layer (B[k][j]: lane half h supplies one k per
+//     step, lane j the sample), so after bias+ReLU the accumulators feed the next layer's MFMAs
+//     directly. Activations never leave the register file: no LDS, no HBM, no barriers. A wave owns
+//     32 samples x all W channels (128 accumulator registers in + 128 out at W = 256, which is why
+//     the kernel runs one wave per SIMD with the 512-entry unified VGPR/AGPR file).
+//   * The k order a layer consumes is therefore "whatever the previous accumulator layout holds";
+//     the weights are re-packed ONCE (nerfail_mlp_pack) into that k order and into the A-fragment
+//     lane order, so each weight read is one fully coalesced 16-byte-per-lane load covering 4 MFMA
+//     k-steps. The 2.4 MB image stays L2-resident; all waves stream it in the same order.
+//   * Positional encoding is computed per lane in registers: MFMA step s of the encoding part needs,
+//     for lane half 0 / 1, sin / cos of the SAME argument x_d*2^f, i.e. one sincosf per step.
+//   * alpha_linear (W->1) and rgb_linear (W/2->3) are too thin for a 32-wide MFMA tile: VALU dot
+//     products on the accumulator registers + one cross-half shuffle.
+// Bound: f32 MFMA (157 TFLOP/s dense on MI355X); algorithmic work 1 186 816 FLOP per sample (D8 W256).
+#include "common.h"
+
+namespace nerfail {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPtsCh = 63, kDirCh = 27;
+constexpr int kEmbQuads = 8;   // 32 k-steps: 30 sin/cos pairs + (x|y) + (z|pad)
+constexpr int kDirQuads = 4;   // 16 k-steps: 12 sin/cos pairs + (x|y) + (z|pad) + 2 zero steps
+
+// Input channel of a positional encoding (RH:47-50 order: x(3), then per band sin(3), cos(3))
+// consumed by k-step s in lane half h; -1 = zero padding. `bands` = 10 (pts) or 4 (dirs).
+__host__ __device__ inline int enc_channel(int s, int h, int bands) {
+    if (s < 3 * bands) return 3 + 6 * (s / 3) + 3 * h + (s % 3);
+    if (s == 3 * bands) return h;               // x | y
+    if (s == 3 * bands + 1) return h ? -1 : 2;  // z | pad
+    return -1;
+}
+// Channel of a 32-channel accumulator tile held in register r of lane half h (32x32 C/D layout).
+__host__ __device__ inline int acc_channel(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct MlpLayout {
+    int NT, D, skip;
+    unsigned w_off[NERFAIL_MAX_DEPTH + 2];   // [0..D-1] pts layers, [D] feature, [D+1] views
+    unsigned b_off[NERFAIL_MAX_DEPTH + 2];
+    unsigned alpha_off, rgb_off, total;
+};
+
+static inline bool layer_has_emb(int l, int skip) { return l == 0 || (skip >= 0 && l == skip + 1); }
+
+static bool make_layout(int D, int W, int skip, MlpLayout& L) {
+    if (!(W == 64 || W == 128 || W == 256)) return false;
+    if (D < 2 || D > NERFAIL_MAX_DEPTH) return false;
+    if (skip >= D - 1) skip = -1;    // `if i in skips` never fires for the last layer's successor (RH:106)
+    L.NT = W / 32; L.D = D; L.skip = skip;
+    const int NT = L.NT, OTV = NT / 2;
+    unsigned off = 0;
+    for (int l = 0; l <= D + 1; ++l) {
+        const int OT = (l == D + 1) ? OTV : NT;
+        int quads = 0;
+        if (l <= D - 1 && layer_has_emb(l, skip)) quads += kEmbQuads;
+        if (l > 0) quads += NT * 4;
+        if (l == D + 1) quads += kDirQuads;
+        L.w_off[l] = off; off += (unsigned)quads * OT * 256;
+        L.b_off[l] = off; off += (unsigned)OT * 32;
+    }
+    L.alpha_off = off; off += (unsigned)NT * 32 + 4;
+    L.rgb_off = off; off += 3u * OTV * 32 + 4;
+    L.total = off;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------- packing
+// One launch per MFMA layer: writes the A-fragment image [quad][tile][lane][4] and the bias image.
+__global__ void pack_layer_kernel(const float* __restrict__ w, const float* __restrict__ b, int out_f, int in_f,
+                                  int OT, int NT, int emb_col0, int h_col0, int dir_col0, float* __restrict__ wq,
+                                  float* __restrict__ bq, int total_w) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < OT * 32) {   // bias image [OT][2][16]
+        const int t = g / 32, hh = (g / 16) & 1, r = g & 15;
+        const int ch = 32 * t + acc_channel(r, hh);
+        bq[g] = (ch < out_f) ? b[ch] : 0.f;
+    }
+    if (g >= total_w) return;
+    const int e = g & 3, lane = (g >> 2) & 63, rest = g >> 8;
+    const int t = rest % OT;
+    int q = rest / OT;
+    const int hh = lane >> 5, row = 32 * t + (lane & 31);
+    int col = -1;
+    if (emb_col0 >= 0) {
+        if (q < kEmbQuads) { const int c = enc_channel(4 * q + e, hh, 10); col = c < 0 ? -1 : emb_col0 + c; q = -1; }
+        else q -= kEmbQuads;
+    }
+    if (q >= 0 && h_col0 >= 0) {
+        if (q < NT * 4) { const int s = 4 * q + e; col = h_col0 + 32 * (s / 16) + acc_channel(s % 16, hh); q = -1; }
+        else q -= NT * 4;
+    }
+    if (q >= 0 && dir_col0 >= 0) {
+        const int c = enc_channel(4 * q + e, hh, 4); col = c < 0 ? -1 : dir_col0 + c;
+    }
+    wq[g] = (row < out_f && col >= 0) ? w[(long)row * in_f + col] : 0.f;
+}
+
+// alpha image [NT][2][16] + bias, rgb image [3][OTV][2][16] + 3 biases
+__global__ void pack_heads_kernel(const float* __restrict__ aw, const float* __restrict__ ab,
+                                  const float* __restrict__ rw, const float* __restrict__ rb, int W,
+                                  float* __restrict__ aq, float* __restrict__ rq) {
+    const int NT = W / 32, OTV = NT / 2;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < NT * 32) {
+        const int t = g / 32, hh = (g / 16) & 1, r = g & 15;
+        aq[g] = aw[32 * t + acc_channel(r, hh)];
+    } else if (g < NT * 32 + 4) {
+        aq[g] = (g == NT * 32) ? ab[0] : 0.f;
+    }
+    if (g < 3 * OTV * 32) {
+        const int c = g / (OTV * 32), rem = g % (OTV * 32);
+        const int t = rem / 32, hh = (rem / 16) & 1, r = rem & 15;
+        rq[g] = rw[c * (W / 2) + 32 * t + acc_channel(r, hh)];
+    } else if (g < 3 * OTV * 32 + 4) {
+        const int c = g - 3 * OTV * 32;
+        rq[g] = (c < 3) ? rb[c] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------- device side
+struct MlpArgs {
+    const float* packed;
+    const float* pts;        // [M,3]      (NULL when xemb is given)
+    const float* viewdirs;   // [rays,3]
+    const float* xemb;       // [M,90] already embedded input, or NULL
+    float* raw;              // [M,4]
+    long M;
+    int spr;                 // samples per ray
+    MlpLayout lay;
+};
+
+template <int OT>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __restrict__ b, int h) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(b + (t * 2 + h) * 16);
+        const f32x4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        acc[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
+                          v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+    }
+}
+
+// One part of a layer: NQ quads of 4 k-steps. Quad q's A fragments (one 16-byte load per out-tile and
+// lane) are requested one quad AHEAD of the 4*OT MFMAs that consume them, so the ~2048 MFMA cycles of a
+// quad cover the L2 latency of the next one (one wave per SIMD: nothing else would hide it).
+// bsel(q, e) yields the B operand (a register of the previous layer / of the encoding) for k-step 4q+e;
+// q and e are compile-time constants after unrolling, so it is a plain register reference.
+template <int OT, int NQ, typename BSel>
+__device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __restrict__ w, int lane, BSel bsel) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
+    f32x4 cur[OT], nxt[OT];
+#pragma unroll
+    for (int t = 0; t < OT; ++t) cur[t] = wp[t * 64];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) nxt[t] = wp[((q + 1) * OT + t) * 64];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][e], bsel(q, e), acc[t], 0, 0, 0);
+        if (q + 1 < NQ) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) cur[t] = nxt[t];
+        }
+    }
+}
+
+template <int OT, int NQ>
+__device__ __forceinline__ void mfma_scalars(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
+                                             const float (&bsrc)[4 * NQ]) {
+    mfma_part<OT, NQ>(acc, w, lane, [&](int q, int e) { return bsrc[4 * q + e]; });
+}
+
+// NT*4 quads whose B operands are the previous layer's accumulator registers
+template <int OT, int NT>
+__device__ __forceinline__ void mfma_acts(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
+                                          const f32x16 (&in)[NT]) {
+    mfma_part<OT, NT * 4>(acc, w, lane, [&](int q, int e) { return in[q >> 2][4 * (q & 3) + e]; });
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_to(f32x16 (&dst)[NT], const f32x16 (&src)[NT], bool relu) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[t][r] = relu ? fmaxf(src[t][r], 0.f) : src[t][r];
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
+    constexpr int OTV = NT / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const float* __restrict__ P = a.packed;
+    const MlpLayout& L = a.lay;
+    const long ntiles = (a.M + 31) / 32;
+    const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);
+
+    for (long rnd = 0; rnd < nrounds; ++rnd) {
+        const long tile = (rnd * gridDim.x + blockIdx.x) * 4 + wave;
+        if (tile >= ntiles) break;     // wave-uniform; waves are fully independent (no barriers)
+        const long sraw = tile * 32 + j;
+        const long s = sraw < a.M ? sraw : a.M - 1;
+
+        // ---- B operands of the encoding parts, in registers
+        float emb[4 * kEmbQuads], demb[4 * kDirQuads];
+        if (a.xemb == nullptr) {
+            const float px[3] = {a.pts[3 * s], a.pts[3 * s + 1], a.pts[3 * s + 2]};
+            const float* vd = a.viewdirs + 3 * (s / a.spr);
+            const float vx[3] = {vd[0], vd[1], vd[2]};
+#pragma unroll
+            for (int f = 0; f < 10; ++f)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float sn, cs;
+                    sincosf(__fmul_rn(px[d], (float)(1 << f)), &sn, &cs);   // x * 2^f exactly as RH:39-41
+                    emb[3 * f + d] = h ? cs : sn;
+                }
+            emb[30] = h ? px[1] : px[0];
+            emb[31] = h ? 0.f : px[2];
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    float sn, cs;
+                    sincosf(__fmul_rn(vx[d], (float)(1 << f)), &sn, &cs);
+                    demb[3 * f + d] = h ? cs : sn;
+                }
+            demb[12] = h ? vx[1] : vx[0];
+            demb[13] = h ? 0.f : vx[2];
+            demb[14] = 0.f; demb[15] = 0.f;
+        } else {
+            const float* x = a.xemb + (kPtsCh + kDirCh) * s;
+#pragma unroll
+            for (int st = 0; st < 4 * kEmbQuads; ++st) {
+                const int c = enc_channel(st, h, 10);
+                emb[st] = c >= 0 ? x[c] : 0.f;
+            }
+#pragma unroll
+            for (int st = 0; st < 4 * kDirQuads; ++st) {
+                const int c = enc_channel(st, h, 4);
+                demb[st] = c >= 0 ? x[kPtsCh + c] : 0.f;
+            }
+        }
+
+        f32x16 act[NT], acc[NT];
+        // ---- layer 0: 63 -> W
+        load_bias<NT>(acc, P + L.b_off[0], h);
+        mfma_scalars<NT, kEmbQuads>(acc, P + L.w_off[0], lane, emb);
+        relu_to<NT>(act, acc, true);
+
+        // ---- layers 1..D-1 (pts_linears, ReLU) and D (feature_linear, no activation)
+        float alpha = 0.f;
+#pragma unroll 1
+        for (int l = 1; l <= L.D; ++l) {
+            if (l == L.D) {   // alpha_linear on the last pts activation (RH:110)
+                const float* wa = P + L.alpha_off;
+                float sacc = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(wa + (t * 2 + h) * 16);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 wv = p[r4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sacc = fmaf(wv[e], act[t][4 * r4 + e], sacc);
+                    }
+                }
+                sacc += __shfl_xor(sacc, 32, 64);
+                alpha = sacc + wa[NT * 32];
+            }
+            load_bias<NT>(acc, P + L.b_off[l], h);
+            const float* w = P + L.w_off[l];
+            if (l == L.skip + 1 && L.skip >= 0) {   // h = cat([input_pts, h]) (RH:106-107)
+                mfma_scalars<NT, kEmbQuads>(acc, w, lane, emb);
+                w += kEmbQuads * NT * 256;
+            }
+            mfma_acts<NT, NT>(acc, w, lane, act);
+            relu_to<NT>(act, acc, l < L.D);
+        }
+
+        // ---- views_linears[0]: cat([feature, embedded dirs]) -> W/2, ReLU (RH:112-116)
+        f32x16 hv[OTV];
+        load_bias<OTV>(hv, P + L.b_off[L.D + 1], h);
+        mfma_acts<OTV, NT>(hv, P + L.w_off[L.D + 1], lane, act);
+        mfma_scalars<OTV, kDirQuads>(hv, P + L.w_off[L.D + 1] + NT * 4 * OTV * 256, lane, demb);
+
+        // ---- rgb_linear: W/2 -> 3 (RH:118)
+        const float* wr = P + L.rgb_off;
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < OTV; ++t) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(wr + ((c * OTV + t) * 2 + h) * 16);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 wv = p[r4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc = fmaf(wv[e], fmaxf(hv[t][4 * r4 + e], 0.f), sacc);
+                }
+            }
+            sacc += __shfl_xor(sacc, 32, 64);
+            rgb[c] = sacc + wr[3 * OTV * 32 + c];
+        }
+        if (h == 0 && sraw < a.M)
+            reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);
+    }
+}
+
+static int launch_mlp(const MlpArgs& a, int W, hipStream_t s) {
+    const long ntiles = (a.M + 31) / 32;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > cus) blocks = cus;      // persistent: one 4-wave workgroup per CU, one wave per SIMD
+    const dim3 grid((unsigned)blocks), block(256);
+    switch (W) {
+        case 256: nerf_mlp_fwd_kernel<8><<<grid, block, 0, s>>>(a); break;
+        case 128: nerf_mlp_fwd_kernel<4><<<grid, block, 0, s>>>(a); break;
+        case 64: nerf_mlp_fwd_kernel<2><<<grid, block, 0, s>>>(a); break;
+        default: set_error("nerfail_mlp_fwd: unsupported W"); return NERFAIL_EINVAL;
+    }
+    NF_LAUNCHED("nerf_mlp_fwd_kernel");
+    return NERFAIL_OK;
+}
+
+}  // namespace nerfail
+
+using namespace nerfail;
+
+extern "C" size_t nerfail_mlp_packed_floats(int D, int W, int skip) {
+    MlpLayout L;
+    return make_layout(D, W, skip, L) ? (size_t)L.total : 0;
+}
+
+extern "C" int nerfail_mlp_pack(const nerfail_mlp_params* p, float* packed, void* stream) {
+    NF_REQUIRE(p != nullptr && packed != nullptr, "NULL pointer");
+    NF_REQUIRE(p->input_ch == kPtsCh && p->input_ch_views == kDirCh, "only multires=10 / multires_views=4 (63 + 27 channels)");
+    MlpLayout L;
+    NF_REQUIRE(make_layout(p->D, p->W, p->skip, L), "unsupported (D, W): W in {64,128,256}, 2 <= D <= 16");
+    for (int i = 0; i < p->D; ++i) NF_REQUIRE(p->pts_w[i] != nullptr && p->pts_b[i] != nullptr, "pts_linears pointer is NULL");
+    NF_REQUIRE(p->views_w && p->views_b && p->feature_w && p->feature_b && p->alpha_w && p->alpha_b && p->rgb_w && p->rgb_b,
+               "head pointer is NULL");
+    hipStream_t s = as_stream(stream);
+    const int W = p->W, NT = L.NT, OTV = NT / 2;
+    for (int l = 0; l <= p->D + 1; ++l) {
+        const bool emb = l <= p->D - 1 && layer_has_emb(l, L.skip);
+        const float *w, *b;
+        int out_f, in_f, OT = NT, emb0 = -1, h0 = -1, dir0 = -1;
+        if (l < p->D) {
+            w = p->pts_w[l]; b = p->pts_b[l]; out_f = W;
+            in_f = (l == 0) ? kPtsCh : (emb ? W + kPtsCh : W);
+            if (emb) emb0 = 0;
+            if (l > 0) h0 = emb ? kPtsCh : 0;
+        } else if (l == p->D) {
+            w = p->feature_w; b = p->feature_b; out_f = W; in_f = W; h0 = 0;
+        } else {
+            w = p->views_w; b = p->views_b; out_f = W / 2; in_f = W + kDirCh; OT = OTV; h0 = 0; dir0 = W;
+        }
+        const int total_w = (int)(L.b_off[l] - L.w_off[l]);
+        const int n = total_w > OT * 32 ? total_w : OT * 32;
+        pack_layer_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(w, b, out_f, in_f, OT, NT, emb0, h0, dir0,
+                                                                      packed + L.w_off[l], packed + L.b_off[l], total_w);
+        NF_LAUNCHED("pack_layer_kernel");
+    }
+    const int nh = (NT * 32 + 4) > (3 * OTV * 32 + 4) ? (NT * 32 + 4) : (3 * OTV * 32 + 4);
+    pack_heads_kernel<<<dim3((nh + 255) / 256), dim3(256), 0, s>>>(p->alpha_w, p->alpha_b, p->rgb_w, p->rgb_b, W,
+                                                                  packed + L.alpha_off, packed + L.rgb_off);
+    NF_LAUNCHED("pack_heads_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, const float* pts, const float* viewdirs,
+                               int64_t M, int samples_per_ray, float* raw, void* stream) {
+    NF_REQUIRE(M >= 0, "M is negative");
+    NF_REQUIRE(samples_per_ray >= 1, "samples_per_ray must be positive");
+    MlpArgs a;
+    NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(packed != nullptr && pts != nullptr && viewdirs != nullptr && raw != nullptr, "NULL pointer");
+    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.raw = raw; a.M = M; a.spr = samples_per_ray;
+    return launch_mlp(a, W, as_stream(stream));
+}
+
+extern "C" int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int skip, const float* x, int64_t M, float* raw,
+                                        void* stream) {
+    NF_REQUIRE(M >= 0, "M is negative");
+    MlpArgs a;
+    NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(packed != nullptr && x != nullptr && raw != nullptr, "NULL pointer");
+    a.packed = packed; a.pts = nullptr; a.viewdirs = nullptr; a.xemb = x; a.raw = raw; a.M = M; a.spr = 1;
+    return launch_mlp(a, W, as_stream(stream));
+}

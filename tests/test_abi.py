@@ -1,0 +1,61 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/nerfail_hip.h
+declares, validates arguments with the documented error codes, and the package fails loudly without a GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'nerfail_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(nerfail_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nerfail_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.nerfail_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_validation_without_gpu():
+    from nerfail_amd import _lib
+    lib = _lib.load()
+    assert lib.nerfail_mlp_packed_floats(8, 256, 4) == 597000
+    assert lib.nerfail_mlp_packed_floats(4, 64, 4) == lib.nerfail_mlp_packed_floats(4, 64, -1)
+    assert lib.nerfail_mlp_packed_floats(8, 100, 4) == 0            # unsupported width
+    assert lib.nerfail_composite(None, None, None, None, 5, 0, 0, None, None, None, None, None, None, None, None) == 1
+    assert b'n_samples' in lib.nerfail_last_error()
+    assert lib.nerfail_knn8(None, 4, None, 3, None, None, None, None) == 1
+    assert b'8 points' in lib.nerfail_last_error()
+    assert lib.nerfail_pack_rays(None, None, 0, 2.0, 6.0, None, None) == 0   # empty input is a no-op
+    assert lib.nerfail_igsm_step(None, None, None, 10, 2.0, 32.0, 0, None, None) == 1
+    with pytest.raises(_lib.NerfailError):
+        _lib.check(lib.nerfail_gauss_weight(None, 1, 1, -1.0, None, None))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only behaviour')
+def test_fails_loudly_without_gpu():
+    from nerfail_amd.run_nerf import raw2outputs
+    from nerfail_amd.GaussNet import create_gauss_w
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        raw2outputs(torch.zeros(2, 64, 4), torch.zeros(2, 64), torch.ones(2, 3))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        create_gauss_w('cpu', 0.02)(torch.zeros(1, 2, 4, 4, 8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'nerfail_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f

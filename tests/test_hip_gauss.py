@@ -1,0 +1,97 @@
+"""-m gpu: gauss path (K9-K12) through the C ABI against the reference's golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_err
+from hiputil import T, N, dev
+from oracle import gauss as OG
+
+pytestmark = pytest.mark.gpu
+
+
+def test_create_gauss_w(golden):
+    from nerfail_amd.GaussNet import create_gauss_w
+    g = golden('g9_gauss_w')
+    i_w, dist = create_gauss_w(dev(), 0.02)(T(g['dist_and_index']))
+    assert rel_err(N(i_w)[:, 0], g['i_w'][:, 0]) < 1e-5
+    assert np.array_equal(N(i_w)[:, 1], g['i_w'][:, 1])
+    assert np.array_equal(N(dist), g['dist'])
+    assert (N(i_w)[0, 0, 0, 0] == 0).all()
+
+
+@pytest.mark.parametrize('tag,eps', [('epsNone_', None), ('eps32_', 32.0)])
+def test_gauss_forward_backward(golden, tag, eps):
+    from nerfail_amd.GaussNet import gauss_gather
+    g = golden('g10_gauss_net')
+    s = T(g['s']).requires_grad_(True)
+    mm = torch.zeros(2, device=dev())
+    x, x_rgba = gauss_gather(s, T(g['wi']), T(g['ori']), eps, mm)
+    assert rel_err(N(x), g[tag + 'x']) < 1e-5
+    assert rel_err(N(x_rgba), g[tag + 'x_rgba']) < 1e-5
+    assert abs(float(mm[1]) - float(g[tag + 'eps3d_max'])) < 1e-3 * abs(float(mm[1]))
+    assert abs(float(mm[0]) - float(g[tag + 'eps3d_min'])) < 1e-3 * abs(float(mm[0]))
+    ((x * T(g['Gx'])).sum() + (x_rgba * T(g['Gr'])).sum()).backward()
+    assert rel_err(N(s.grad), g[tag + 'grad_s']) < 1e-4     # float atomics: order-dependent last bits
+
+
+@pytest.mark.parametrize('tag,eps', [('epsNone_', None), ('eps32_', 32.0)])
+def test_gauss_net_module_end_to_end(golden, tag, eps):
+    """gauss_net.forward with the fixture's stand-in classifier: logits and d CE / d s vs the reference's autograd."""
+    from nerfail_amd.GaussNet import gauss_net
+    g = golden('g10_gauss_net')
+    w = T(g['cls_w'])
+
+    class Cls(torch.nn.Module):
+        def forward(self, x):
+            return torch.nn.functional.adaptive_avg_pool2d(x, 4).reshape(x.shape[0], -1) @ w.t()
+    net = gauss_net(dev(), 0.02, Cls(), 'my_model', epsilon=eps)
+    s = T(g['s']).requires_grad_(True)
+    x, x_rgba, cla, ori, ori_cla = net(s, T(g['wi']), T(g['ori']))
+    assert rel_err(N(cla), g[tag + 'cla']) < 1e-4
+    torch.nn.functional.cross_entropy(cla, torch.full((2,), 4, dtype=torch.long, device=dev())).backward()
+    assert rel_err(N(s.grad), g[tag + 'ce_grad_s']) < 1e-4
+    assert net.epsilon_3d_max > 0 and net.epsilon_3d_min < 0
+    net.epsilon_3d_zero()
+    assert net.epsilon_3d_max == 0
+
+
+def test_igsm_step(golden):
+    from nerfail_amd.attack import igsm_step
+    g = golden('g11_igsm_step')
+    for targeted in (False, True):
+        out = igsm_step(T(g['s']), T(g['grad']), T(g['s_init']), 2.0, 32.0, targeted)
+        assert np.array_equal(N(out), g['out_targeted%d' % int(targeted)])
+
+
+def test_gauss_full_size_properties():
+    """cfg3 sizes: P=3 base views, 800x800 pixels, B=2 views. Linearity of x in s, adjointness of the backward."""
+    from nerfail_amd.GaussNet import gauss_gather, create_gauss_w
+    rs = np.random.RandomState(0)
+    P, B, H, W = 3, 2, 800, 800
+    idx = rs.randint(0, P * H * W, size=(B, H, W, 8)).astype(np.float32)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    wi, _ = create_gauss_w(dev(), 0.02)(T(np.stack([dist, idx], 1)))
+    ori = T(synth.disc_alpha_image(B, H, W, seed=3))
+    s1 = T(rs.uniform(-20, 20, (P, H, W, 4)).astype(np.float32))
+    s2 = T(rs.uniform(-20, 20, (P, H, W, 4)).astype(np.float32))
+    x1, _ = gauss_gather(s1, wi, ori, None)
+    x2, _ = gauss_gather(s2, wi, ori, None)
+    x12, _ = gauss_gather(s1 + s2, wi, ori, None)
+    assert rel_err(N(x12), N(x1 + x2)) < 1e-5                              # x is linear in s
+    # <G, J ds> == <J^T G, ds> for the linear part (x only)
+    G = T(rs.normal(size=(B, H, W, 4)).astype(np.float32))
+    s = s1.clone().requires_grad_(True)
+    x, _ = gauss_gather(s, wi, ori, None)
+    (x * G).sum().backward()
+    lhs = float((x2.double() * G.double()).sum())
+    rhs = float((s.grad.double() * s2.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), abs(rhs), 1.0) * 10
+    # weights of every pixel sum to <= 1 and are non-negative
+    wsum = N(wi[:, 0].sum(-1))
+    assert (wsum <= 1 + 1e-5).all() and (N(wi[:, 0]) >= 0).all()
+    # spot check 1 row of pixels against the oracle
+    xs, xr, _ = OG.gauss_forward(N(s1), N(wi)[:, :, 400:401], N(ori)[:, 400:401], 32.0)
+    xh, xrh = gauss_gather(s1, wi[:, :, 400:401].contiguous(), ori[:, 400:401].contiguous(), 32.0)
+    assert rel_err(N(xh), xs) < 1e-5 and rel_err(N(xrh), xr) < 1e-5

@@ -1,0 +1,240 @@
+"""-m gpu: the HIP render path (through the C ABI) against the golden vectors of the reference and the oracle.
+
+Tolerance: 1e-4 relative float32 (BASELINE.json north_star) measured by conftest.rel_err; tighter where the
+kernel is elementwise. Per-sample `raw` / `weights` carry reference-inherent sensitivities documented in
+tests/test_oracle_nerf.py and get the same treatment here.
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_err
+from hiputil import T, N, hip_nerf, dev
+from oracle import nerf as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_is_gfx950():
+    from nerfail_amd import _lib
+    assert 'gfx950' in _lib.device_name()
+
+
+def test_get_rays_and_ray_gen(golden):
+    from nerfail_amd.run_nerf_helpers import get_rays
+    from nerfail_amd.run_nerf import ray_gen, _pack_rays
+    g = golden('g1_get_rays')
+    ro, rd = get_rays(16, 16, g['K16'], g['c2w16'])
+    assert np.array_equal(N(ro), g['rays_o16'])
+    assert rel_err(N(rd), g['rays_d16']) < 1e-6
+    ro, rd = get_rays(800, 800, g['K800'], g['c2w800'])
+    assert rel_err(N(rd)[g['jj800'], g['ii800']], g['rays_d800']) < 1e-6
+    # bit-exact against the oracle's operation order, non-square image
+    H, W = 37, 53
+    focal, K = synth.lego_intrinsics(H, W)
+    c2w = synth.pose_spherical(40., -30., 4.)[:3, :4]
+    oo, od = O.get_rays(H, W, K, c2w)
+    ro, rd = get_rays(H, W, K, c2w)
+    assert np.array_equal(N(ro), oo) and np.array_equal(N(rd), od)
+    # packed rays of a pixel range == pack(get_rays)[range] (the multi-GPU shard unit), and == oracle packing
+    full = N(_pack_rays(ro, rd, 2., 6.))
+    assert rel_err(full, O.pack_rays(oo, od, 2., 6.)) < 1e-6
+    part = N(ray_gen(H, W, K, c2w, 2., 6., pix_begin=101, pix_count=777))
+    assert np.array_equal(part, full[101:101 + 777])
+    assert ray_gen(H, W, K, c2w, 2., 6., pix_begin=5, pix_count=0).shape == (0, 11)
+
+
+def test_embed(golden):
+    from nerfail_amd.run_nerf_helpers import get_embedder
+    g = golden('g2_embed')
+    e10, d10 = get_embedder(10, 0)
+    e4, d4 = get_embedder(4, 0)
+    assert (d10, d4) == (63, 27)
+    assert np.abs(N(e10(T(g['pts']))) - g['emb_pts']).max() < 1e-6
+    assert np.abs(N(e4(T(g['dirs']))) - g['emb_dirs']).max() < 1e-6
+
+
+@pytest.mark.parametrize('D,W', [(8, 256), (4, 64)])
+def test_nerf_forward_embedded(golden, D, W):
+    g = golden('g3_nerf_forward')
+    sd, net = hip_nerf(D, W, int(g['seed_D%dW%d' % (D, W)]))
+    emb = np.concatenate([O.embed(g['pts'], 10), O.embed(g['dirs'], 4)], -1)
+    raw = N(net(T(emb)))
+    assert rel_err(raw, g['raw_D%dW%d' % (D, W)]) < 1e-4
+    assert rel_err(raw, O.nerf_forward(sd, emb, D=D, W=W)) < 1e-4
+    # ragged sizes: 1, 31, 33 samples (tiles are 32 wide)
+    for m in (1, 31, 33):
+        assert rel_err(N(net(T(emb[:m]))), g['raw_D%dW%d' % (D, W)][:m]) < 1e-4
+
+
+def test_nerf_state_dict_keys_match_reference():
+    sd, net = hip_nerf(8, 256, 3)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+
+
+def test_run_network_fused(golden):
+    from nerfail_amd.run_nerf import run_network
+    from nerfail_amd.run_nerf_helpers import get_embedder
+    g = golden('g3_nerf_forward')
+    sd, net = hip_nerf(8, 256, 10)
+    e10, _ = get_embedder(10, 0)
+    e4, _ = get_embedder(4, 0)
+    raw = run_network(T(g['pts'].reshape(8, 64, 3)), T(g['dirs'][:8]), net, e10, e4, netchunk=1024 * 64)
+    assert rel_err(N(raw), g['run_network_raw']) < 1e-4
+    # weights changed in place -> the packed image must be rebuilt
+    with torch.no_grad():
+        net.rgb_linear.bias.add_(1.0)
+    raw2 = run_network(T(g['pts'].reshape(8, 64, 3)), T(g['dirs'][:8]), net, e10, e4)
+    assert np.abs(N(raw2)[..., :3] - (g['run_network_raw'][..., :3] + 1.0)).max() < 1e-4
+
+
+def test_raw2outputs(golden):
+    from nerfail_amd.run_nerf import raw2outputs
+    g = golden('g4_raw2outputs')
+    for Ns in (64, 192):
+        raw, z, rd = g['N%d_raw' % Ns], g['N%d_z' % Ns], g['N%d_rays_d' % Ns]
+        for wb in (False, True):
+            out = raw2outputs(T(raw), T(z), T(rd), 0, wb)
+            for k, v in zip(('rgb', 'disp', 'acc', 'weights', 'depth'), out):
+                ref = g['N%d_wb%d_%s' % (Ns, int(wb), k)]
+                assert rel_err(N(v), ref) < (1e-4 if k == 'weights' else 1e-5), (Ns, wb, k)
+        out = raw2outputs(T(raw), T(z), T(rd), 0.5, True, noise=T(g['N%d_noise' % Ns] * np.float32(0.5)))
+        for k, v in zip(('rgb', 'disp', 'acc', 'weights', 'depth'), out):
+            assert rel_err(N(v), g['N%d_noise_%s' % (Ns, k)]) < (1e-4 if k == 'weights' else 1e-5), (Ns, k)
+    # other sample counts (1, 2, 65, 100, 256) against the oracle; empty batch
+    rs = np.random.RandomState(0)
+    for Ns in (1, 2, 65, 100, 256):
+        z = np.sort(rs.uniform(2, 6, (7, Ns)).astype(np.float32), -1)
+        raw = rs.normal(size=(7, Ns, 4)).astype(np.float32) * 3
+        rd = rs.normal(size=(7, 3)).astype(np.float32)
+        ref = O.raw2outputs(raw, z, rd, None, True)
+        out = raw2outputs(T(raw), T(z), T(rd), 0, True)
+        for k, v, r in zip(('rgb', 'disp', 'acc', 'weights', 'depth'), out, ref):
+            assert rel_err(N(v), r) < 1e-4, (Ns, k)
+    out = raw2outputs(torch.empty((0, 64, 4), device=dev()), torch.empty((0, 64), device=dev()),
+                      torch.empty((0, 3), device=dev()))
+    assert out[0].shape == (0, 3)
+
+
+def _check_samples(got, ref, u, bins):
+    last_bin = (bins[:, -1] - bins[:, -2])[:, None] * 1.0001
+    edge = u >= np.float32(0.999999)
+    assert rel_err(np.where(edge, ref, got), ref) < 1e-5
+    assert (np.abs(got - ref) <= last_bin)[edge].all()
+
+
+def test_sample_pdf(golden):
+    from nerfail_amd.run_nerf_helpers import sample_pdf
+    g = golden('g5_sample_pdf')
+    det = N(sample_pdf(T(g['bins']), T(g['weights']), 128, det=True))
+    _check_samples(det, g['det'], np.broadcast_to(O.torch_linspace01(128), det.shape), g['bins'])
+    rnd = N(sample_pdf(T(g['bins']), T(g['weights']), 128, det=False, u=T(g['u'])))
+    _check_samples(rnd, g['rnd'], g['u'], g['bins'])
+    # pytest=True draws from numpy seed 0 exactly like RH:215-223
+    a = N(sample_pdf(T(g['bins']), T(g['weights']), 16, det=False, pytest=True))
+    np.random.seed(0)
+    uu = np.random.rand(48, 16).astype(np.float32)
+    _check_samples(a, O.sample_pdf(g['bins'], g['weights'], 16, u=uu), uu, g['bins'])
+
+
+def test_render_rays_cfg1(golden):
+    from nerfail_amd import run_nerf as RN
+    g = golden('g6_render_rays')
+    sd, net = hip_nerf(4, 64, int(g['cfg1_seed']))
+    r = RN.render_rays(T(g['cfg1_rays']), net, None, 64, retraw=True, white_bkgd=True)
+    for k in ('rgb_map', 'disp_map', 'acc_map', 'raw'):
+        assert rel_err(N(r[k]), g['cfg1_' + k]) < 1e-4, k
+    assert 'rgb0' not in r and 'pts_max' not in r
+
+
+def test_render_rays_cfg2(golden):
+    from nerfail_amd import nerf_to_coord as NC, run_nerf as RN
+    g = golden('g6_render_rays')
+    _, coarse = hip_nerf(8, 256, int(g['cfg2_seed_coarse']))
+    _, fine = hip_nerf(8, 256, int(g['cfg2_seed_fine']))
+    keys = ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'pts_max')
+    r = NC.render_rays(T(g['cfg2_rays']), coarse, None, 64, retraw=True, N_importance=128, network_fine=fine,
+                       white_bkgd=True)
+    for k in keys:
+        assert rel_err(N(r[k]), g['cfg2_det_' + k]) < 1e-4, k
+    assert rel_err(N(r['raw']), g['cfg2_det_raw']) < 1e-2
+    r = NC.render_rays(T(g['cfg2_rays']), coarse, None, 64, retraw=True, N_importance=128, network_fine=fine,
+                       white_bkgd=True, perturb=1., t_rand=T(g['cfg2_t_rand']), u=T(g['cfg2_u']))
+    for k in keys:
+        assert rel_err(N(r[k]), g['cfg2_pert_' + k]) < 1e-4, k
+    # the run_nerf flavour has no pts_max and the same maps
+    r2 = RN.render_rays(T(g['cfg2_rays']), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True)
+    assert 'pts_max' not in r2
+    assert rel_err(N(r2['rgb_map']), g['cfg2_det_rgb_map']) < 1e-4
+
+
+def test_render_wrapper(golden):
+    from nerfail_amd import nerf_to_coord as NC, run_nerf as RN
+    g = golden('g6_render_rays')
+    _, coarse = hip_nerf(8, 256, 21)
+    _, fine = hip_nerf(8, 256, 22)
+    q = RN.FusedNetworkQuery(RN.get_embedder(10, 0)[0], RN.get_embedder(4, 0)[0])
+    kw = dict(network_query_fn=q, perturb=0., N_importance=128, network_fine=fine, N_samples=64, network_fn=coarse,
+              use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+    rgb, disp, acc, pts_max, extras = NC.render(8, 8, g['render_K'], chunk=40, c2w=T(g['render_c2w']), near=2., far=6., **kw)
+    assert rgb.shape == (8, 8, 3) and disp.shape == (8, 8) and pts_max.shape == (8, 8, 3)
+    for v, gk in ((rgb, 'render_rgb'), (disp, 'render_disp'), (acc, 'render_acc'), (pts_max, 'render_pts_max'),
+                  (extras['rgb0'], 'render_rgb0'), (extras['z_std'], 'render_z_std')):
+        assert rel_err(N(v), g[gk]) < 1e-4, gk
+    # rays= form (training path RN:776): same pixels given as explicit (rays_o, rays_d)
+    ro, rd = RN.get_rays(8, 8, g['render_K'], T(g['render_c2w']))
+    out = RN.render(8, 8, g['render_K'], chunk=1024, rays=(ro.reshape(-1, 3), rd.reshape(-1, 3)), near=2., far=6., **kw)
+    assert rel_err(N(out[0]).reshape(8, 8, 3), g['render_rgb']) < 1e-4
+    assert len(out) == 4 and set(out[3].keys()) == {'rgb0', 'disp0', 'acc0', 'z_std'}
+
+
+def test_render_full_size_properties():
+    """cfg2 sizes (64+128, D=8 W=256) on a 32 768-ray chunk of an 800x800 view: size-independent properties."""
+    from nerfail_amd import nerf_to_coord as NC
+    from nerfail_amd.run_nerf import ray_gen
+    _, coarse = hip_nerf(8, 256, 21)
+    _, fine = hip_nerf(8, 256, 22)
+    focal, K = synth.lego_intrinsics(800, 800)
+    c2w = synth.pose_spherical(-117., -30., 4.)[:3, :4]
+    rays = ray_gen(800, 800, K, c2w, 2., 6., pix_begin=300 * 800, pix_count=32768)
+    kw = dict(N_importance=128, network_fine=fine, white_bkgd=True, retraw=False)
+    a = NC.render_rays(rays, coarse, None, 64, **kw)
+    b = NC.render_rays(rays, coarse, None, 64, **kw)
+    for k in a:                                            # deterministic: bitwise idempotent
+        assert torch.equal(a[k].nan_to_num(7.), b[k].nan_to_num(7.)), k
+    parts = [NC.render_rays(rays[s:s + 5000], coarse, None, 64, **kw) for s in range(0, 32768, 5000)]
+    for k in a:                                            # chunk / shard invariance: bitwise
+        cat = torch.cat([p[k] for p in parts], 0)
+        assert torch.equal(a[k].nan_to_num(7.), cat.nan_to_num(7.)), k
+    acc, rgb = N(a['acc_map']), N(a['rgb_map'])
+    assert np.isfinite(rgb).all() and (acc >= 0).all() and (acc <= 1 + 1e-5).all()
+    assert (rgb >= -1e-5).all() and (rgb <= 1 + 1e-5).all()          # white background composite stays in [0,1]
+    assert (N(a['z_std']) >= 0).all()
+    # spot-check 64 rays of the big chunk against the oracle
+    sel = np.arange(0, 32768, 512)
+    sc, sf = synth.nerf_state_dict(seed=21), synth.nerf_state_dict(seed=22)
+    ref = O.render_rays(N(rays)[sel], sc, 64, 128, sf, white_bkgd=True)
+    for k in ('rgb_map', 'acc_map', 'disp_map', 'pts_max', 'z_std'):
+        assert rel_err(N(a[k])[sel], ref[k]) < 1e-4, k
+
+
+def test_sample_fine_sorted_and_matches_oracle():
+    from nerfail_amd import run_nerf as RN
+    rays = synth.ray_batch(33, seed=9)
+    sd, net = hip_nerf(4, 64, 5)
+    rs = np.random.RandomState(1)
+    u = rs.uniform(size=(33, 128)).astype(np.float32)
+    t_rand = rs.uniform(size=(33, 64)).astype(np.float32)
+    r = RN.render_rays(T(rays), net, None, 64, N_importance=128, white_bkgd=True, perturb=1., t_rand=T(t_rand), u=T(u),
+                       retraw=True, want_pts_max=True)
+    ref = O.render_rays(rays, sd, 64, 128, None, white_bkgd=True, t_rand=t_rand, u=u, D=4, W=64)
+    for k in ('rgb_map', 'acc_map', 'z_std', 'rgb0', 'pts_max'):
+        assert rel_err(N(r[k]), ref[k]) < 1e-4, k
+
+
+def test_cpu_tensors_are_moved_not_computed_on_cpu():
+    """Inputs on the CPU are copied to the GPU; outputs always live on the GPU (there is no CPU path)."""
+    from nerfail_amd.run_nerf import raw2outputs
+    out = raw2outputs(torch.zeros(2, 64, 4), torch.linspace(2, 6, 64).repeat(2, 1), torch.ones(2, 3))
+    assert out[0].is_cuda
