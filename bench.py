@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py - the reference's headline workload on MI355X: full-image NeRF render, Blender-lego shape.
+
+One "step" = one pass of the hot path over one synthetic 800x800 view (BASELINE.json configs[1]):
+ray generation -> 64 coarse samples -> fused posenc+MLP (D=8, W=256) -> composite -> 128 importance
+samples (sorted merge) -> fine MLP -> composite + per-pixel argmax point (nerf_to_coord's render).
+Everything is resident in HBM when the timed region starts; weights are seeded random (no dataset /
+checkpoint in the container); poses follow load_blender.py's pose_spherical.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Multi-GPU: rays / views are independent units, so each rank renders its own view with NO data-path
+collective ("scaling": "weak": per-GPU work fixed). Rank 0 prints ONE JSON line with whole-job rays/s,
+the roofline of the dominant kernel (nerf_mlp_fwd_kernel, f32 MFMA bound; HIP-event timed on the launch
+stream inside the timed region) and a CPU baseline (the numpy oracle on a bounded ray sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import synth  # noqa: E402
+
+H = W = 800
+N_SAMPLES, N_IMPORTANCE = 64, 128
+NET_D, NET_W = 8, 256
+# MACs per sample = 63*256 + 4*256^2 + 319*256 + 2*256^2 (pts) + 256 (alpha)
+# + 65536 (feature) + 283*128 (views) + 384 (rgb) = 593 408
+FLOP_PER_SAMPLE = 2 * 593408
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def make_net(seed, dev):
+    from nerfail_amd.run_nerf_helpers import NeRF
+    sd = synth.nerf_state_dict(D=NET_D, W=NET_W, seed=seed)
+    m = NeRF(D=NET_D, W=NET_W, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd, m.to(dev)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The numpy oracle (CPU port of the reference path) on rays 320000:320000+n of pose 0, n sized to ~20 s."""
+    from oracle import nerf as O
+    sc, sf = synth.nerf_state_dict(seed=21), synth.nerf_state_dict(seed=22)
+    focal, K = synth.lego_intrinsics(H, W)
+    c2w = synth.pose_spherical(-180., -30., 4.)[:3, :4]
+    ro, rd = O.get_rays(H, W, K, c2w)
+    rays = O.pack_rays(ro, rd, 2., 6.)
+    O.render_rays(rays[320000:320128], sc, N_SAMPLES, N_IMPORTANCE, sf, white_bkgd=True)      # warm-up (BLAS threads)
+    t = time.time()
+    O.render_rays(rays[320128:320384], sc, N_SAMPLES, N_IMPORTANCE, sf, white_bkgd=True)
+    per_ray = (time.time() - t) / 256
+    n = int(max(256, min(8192, seconds_budget / per_ray)) // 256 * 256)
+    t = time.time()
+    for s in range(0, n, 1024):
+        O.render_rays(rays[320000 + s:320000 + min(n, s + 1024)], sc, N_SAMPLES, N_IMPORTANCE, sf, white_bkgd=True)
+    dt = time.time() - t
+    return {'value': n / dt, 'unit': 'rays/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': '%d rays (pixels 320000..) of the same 800x800 view, 64+128 samples, D=8 W=256, numpy oracle '
+                      '(oracle/nerf.py, OpenBLAS sgemm on all host cores), %.1f s' % (n, dt)}
+
+
+def attack_gauss_bench(dev, iters=5):
+    """Gauss-path-only NeRFail-S iteration: 8 views x (K10 fwd + K11 bwd) + K12 with a fixed
+    upstream gradient standing in for the classifier. Returns iters/s and the HBM roofline numbers."""
+    from nerfail_amd.GaussNet import gauss_gather, create_gauss_w
+    from nerfail_amd.attack import igsm_step
+    rs = np.random.RandomState(0)
+    P, B = 3, 8
+    Ns = P * H * W
+    # neighbours drawn near the pixel's own index in one base view: locality like a real 8-NN map
+    base = (rs.randint(0, P, size=(B, 1, 1, 1)) * H * W + np.arange(H * W).reshape(1, H, W, 1))
+    idx = np.clip(base + rs.randint(-2 * W, 2 * W, size=(B, H, W, 8)), 0, Ns - 1).astype(np.float32)
+    dist_ = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    wi, _ = create_gauss_w(dev, 0.02)(torch.from_numpy(np.stack([dist_, idx], 1)).to(dev))
+    ori = torch.from_numpy(synth.disc_alpha_image(B, H, W, seed=3)).to(dev)
+    s_init = torch.zeros((P, H, W, 4), device=dev)
+    s_init[..., 3] = 255.0
+    s = s_init.clone()
+    G = torch.from_numpy(rs.normal(size=(B, H, W, 4)).astype(np.float32)).to(dev)
+
+    def one_iter(s):
+        st = s.detach().requires_grad_(True)
+        x, x_rgba = gauss_gather(st, wi, ori, None)
+        (x_rgba * G).sum().backward()
+        return igsm_step(st.detach(), st.grad, s_init, 2.0, 32.0, False)
+    s = one_iter(s)
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(iters):
+        s = one_iter(s)
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / iters
+    alg_bytes = 8 * (102.4e6 + 81.9e6) + 122.9e6        # 1.60 GB / iteration
+    return {'attack_gauss_path_iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3, 'batch_views': B,
+            'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None},
+            'note': 'classifier replaced by a fixed upstream gradient; includes torch autograd glue (x_rgba*G).sum()'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-attack', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+
+    from nerfail_amd import nerf_to_coord as NC, run_nerf as RN
+
+    _, coarse = make_net(21, dev)
+    _, fine = make_net(22, dev)
+    coarse.packed(), fine.packed()
+    focal, K = synth.lego_intrinsics(H, W)
+    thetas = np.linspace(-180, 180, 41)[:-1]
+    kw = dict(network_query_fn=None, perturb=0., N_importance=N_IMPORTANCE, network_fine=fine, N_samples=N_SAMPLES,
+              network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+
+    mlp_events = []
+    orig_mlp = RN._mlp_points
+
+    def timed_mlp(fn, pts, viewdirs):       # HIP events on the stream the kernel is launched on (torch's current)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_mlp(fn, pts, viewdirs)
+        e1.record()
+        mlp_events.append((e0, e1, pts.shape[0] * pts.shape[1]))
+        return out
+    RN._mlp_points = timed_mlp
+
+    def step(i):
+        c2w = synth.pose_spherical(float(thetas[(i * world + rank) % len(thetas)]), -30., 4.)[:3, :4]
+        return NC.render(H, W, K, chunk=H * W, c2w=torch.from_numpy(c2w), near=2., far=6., **kw)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    mlp_events.clear()
+    t0 = time.time()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    barrier()
+    elapsed = time.time() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    assert torch.isfinite(out[0]).all()
+
+    mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in mlp_events)
+    mlp_samples = sum(n for _, _, n in mlp_events)
+    achieved = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+
+    if rank == 0:
+        rays_total = world * args.steps * H * W
+        line = {
+            'metric': 'rays/sec', 'value': rays_total / elapsed, 'unit': 'rays/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'Blender-lego-shaped 800x800 full render incl. per-pixel argmax point '
+                                   '(nerf_to_coord.render), 64+128 samples, D=8 W=256 coarse+fine, white_bkgd, '
+                                   'one view per step per GPU (BASELINE.json configs[1])',
+                       'rays_per_step_per_gpu': H * W, 'chunk': H * W, 'pass': 'forward (render)',
+                       'parallelism': 'view-per-rank, no collective'},
+            'roofline': {'bound': 'mfma', 'kernel': 'nerf_mlp_fwd_kernel<8>', 'achieved': achieved,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                         'traffic': None, 'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
+                         'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline()
+        else:
+            line['cpu_baseline'] = None
+        if not args.no_attack and world == 1:
+            line['extra'] = attack_gauss_bench(dev)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

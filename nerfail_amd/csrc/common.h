@@ -66,6 +66,11 @@ __device__ __forceinline__ double wave_scan_add_f64(double v, int lane) {
     return v;
 }
 
+// Correctly rounded float32 sqrt. NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS the HIP headers
+// map that to __ocml_native_sqrt_f32 (approximate). sqrtf is IEEE-rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt, like the `/` behind __fdiv_rn.
+__device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+
 // pts = o + d*z with the reference's rounding (multiply, then add; no FMA): RN:381
 __device__ __forceinline__ float mul_add_rn(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }
 

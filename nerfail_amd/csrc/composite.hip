@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
 
     const float* rr = rays + NERFAIL_RAY_FLOATS * ray;
     const float dx = rr[3], dy = rr[4], dz = rr[5];
-    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float nrm = sqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
 
     const long base = ray * N;
     const int i0 = lane * IPL;
@@ -114,7 +114,7 @@ extern "C" int nerfail_composite(const float* raw, const float* z_vals, const fl
                                  float* acc_map, float* weights, float* depth_map, const float* pts, float* pts_max,
                                  void* stream) {
     NF_REQUIRE(n_rays >= 0, "n_rays is negative");
-    NF_REQUIRE(n_samples >= 1 && n_samples <= 256, "n_samples must be in [1, 256]");
+    NF_REQUIRE(n_samples >= 2 && n_samples <= 256, "n_samples must be in [2, 256] (the reference fails on a single sample: empty dists, RN:277-278)");
     if (n_rays == 0) return NERFAIL_OK;
     NF_REQUIRE(raw != nullptr && z_vals != nullptr && rays != nullptr, "raw / z_vals / rays is NULL");
     NF_REQUIRE(rgb_map != nullptr && disp_map != nullptr && acc_map != nullptr, "rgb_map / disp_map / acc_map is NULL");

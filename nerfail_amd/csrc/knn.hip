@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void knn8_kernel(const float* __restrict__ que
         if (qi[q] >= nq) continue;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            dist[8 * qi[q] + k] = __fsqrt_rn(top[q].d[k]);
+            dist[8 * qi[q] + k] = sqrt_rn(top[q].d[k]);
             if (idx_f != nullptr) idx_f[8 * qi[q] + k] = (float)top[q].i[k];
             if (idx_i != nullptr) idx_i[8 * qi[q] + k] = top[q].i[k];
         }

@@ -28,7 +28,7 @@ __device__ __forceinline__ void pixel_ray(const Cam& c, int col, int row, float*
 }
 
 __device__ __forceinline__ void viewdir_of(const float* d, float* v) {
-    const float n = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    const float n = sqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
 #pragma unroll
     for (int a = 0; a < 3; ++a) v[a] = __fdiv_rn(d[a], n);
 }

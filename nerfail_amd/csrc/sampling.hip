@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
         svar += dlt * dlt;
     }
     svar = wave_sum(svar);
-    if (lane == 0) z_std[ray] = __fsqrt_rn(svar / (float)nf);
+    if (lane == 0) z_std[ray] = sqrt_rn(svar / (float)nf);
     for (int i = nt + lane; i < ((nt + 3) & ~3); i += 64) zin[i] = INFINITY;   // pad for the float4 sweep
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -79,7 +79,7 @@ def test_gauss_full_size_properties():
     x1, _ = gauss_gather(s1, wi, ori, None)
     x2, _ = gauss_gather(s2, wi, ori, None)
     x12, _ = gauss_gather(s1 + s2, wi, ori, None)
-    assert rel_err(N(x12), N(x1 + x2)) < 1e-5                              # x is linear in s
+    assert np.abs(N(x12) - N(x1 + x2)).max() < 1e-4                        # x is linear in s (|x| ~ 20, fp32)
     # <G, J ds> == <J^T G, ds> for the linear part (x only)
     G = T(rs.normal(size=(B, H, W, 4)).astype(np.float32))
     s = s1.clone().requires_grad_(True)
