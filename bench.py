@@ -71,11 +71,26 @@ def cpu_baseline(seconds_budget=20.0):
                       '(oracle/nerf.py, OpenBLAS sgemm on all host cores), %.1f s' % (n, dt)}
 
 
-def attack_gauss_bench(dev, iters=5):
-    """Gauss-path-only NeRFail-S iteration: 8 views x (K10 fwd + K11 bwd) + K12 with a fixed
-    upstream gradient standing in for the classifier. Returns iters/s and the HBM roofline numbers."""
-    from nerfail_amd.GaussNet import gauss_gather, create_gauss_w
-    from nerfail_amd.attack import igsm_step
+def victim_cnn(num_classes=8):
+    """Stand-in victim with the shape of the reference's 800x800 classifier (model/MyModel.py:5-52: seven
+    3x3 conv + ReLU + 2x2 max-pool stages 3-32-64-128-256-256-128-64, then 1024-512-classes). Stock PyTorch
+    (MIOpen) - the classifier is outside the hot path."""
+    chans = [3, 32, 64, 128, 256, 256, 128, 64]
+    layers = []
+    for cin, cout in zip(chans[:-1], chans[1:]):
+        layers += [torch.nn.Conv2d(cin, cout, 3), torch.nn.ReLU(), torch.nn.MaxPool2d(2)]
+    layers += [torch.nn.Flatten(), torch.nn.Linear(1024, 512), torch.nn.ReLU(), torch.nn.Linear(512, num_classes)]
+    return torch.nn.Sequential(*layers)
+
+
+def attack_bench(dev, iters=5):
+    """NeRFail-S iteration (AS:304-392) on one batch of 8 views, 800x800, P=3 base views.
+    (i) gauss path only: K10 fwd + K11 bwd (deterministic inverted-index form) + K12, the classifier replaced by a
+        fixed upstream gradient; against the 1.60 GB/iteration HBM roofline of SURVEY.md section 8(d).
+    (ii) end to end through gauss_net.forward with the stand-in victim CNN (2 classifier forwards + 1 backward per
+        step, as the reference does)."""
+    from nerfail_amd.GaussNet import gauss_gather, create_gauss_w, gauss_net
+    from nerfail_amd.attack import igsm_step, nerfail_s_step
     rs = np.random.RandomState(0)
     P, B = 3, 8
     Ns = P * H * W
@@ -87,26 +102,40 @@ def attack_gauss_bench(dev, iters=5):
     ori = torch.from_numpy(synth.disc_alpha_image(B, H, W, seed=3)).to(dev)
     s_init = torch.zeros((P, H, W, 4), device=dev)
     s_init[..., 3] = 255.0
-    s = s_init.clone()
     G = torch.from_numpy(rs.normal(size=(B, H, W, 4)).astype(np.float32)).to(dev)
+    out = {}
 
-    def one_iter(s):
-        st = s.detach().requires_grad_(True)
-        x, x_rgba = gauss_gather(st, wi, ori, None)
-        (x_rgba * G).sum().backward()
-        return igsm_step(st.detach(), st.grad, s_init, 2.0, 32.0, False)
-    s = one_iter(s)
-    torch.cuda.synchronize()
-    t = time.time()
-    for _ in range(iters):
-        s = one_iter(s)
-    torch.cuda.synchronize()
-    dt = (time.time() - t) / iters
-    alg_bytes = 8 * (102.4e6 + 81.9e6) + 122.9e6        # 1.60 GB / iteration
-    return {'attack_gauss_path_iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3, 'batch_views': B,
+    def timed(fn, s):
+        s = fn(s)                       # warm-up (builds the inverted index / MIOpen plans once)
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(iters):
+            s = fn(s)
+        torch.cuda.synchronize()
+        return (time.time() - t) / iters
+
+    for det in (True, False):
+        def one_iter(s, det=det):
+            st = s.detach().requires_grad_(True)
+            x, x_rgba = gauss_gather(st, wi, ori, None, None, det)
+            x_rgba.backward(G)
+            return igsm_step(st.detach(), st.grad, s_init, 2.0, 32.0, False)
+        dt = timed(one_iter, s_init.clone())
+        alg_bytes = 8 * (102.4e6 + 81.9e6) + 122.9e6        # 1.60 GB / iteration
+        out['gauss_path_' + ('deterministic' if det else 'atomics')] = {
+            'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
             'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None},
-            'note': 'classifier replaced by a fixed upstream gradient; includes torch autograd glue (x_rgba*G).sum()'}
+                         'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
+
+    torch.manual_seed(0)
+    net = gauss_net(dev, 0.02, victim_cnn(8).to(dev), 'my_model', epsilon=None)
+    label = torch.tensor(4, device=dev)
+    dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
+    out['end_to_end_victim_cnn'] = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
+                                    'note': 'gauss_net.forward (2 classifier forwards) + CE + backward + sign step'}
+    out['batch_views'] = B
+    out['unit'] = 'NeRFail-S iterations/s (batch of 8 views, 800x800, P=3)'
+    return out
 
 
 def main():
@@ -201,7 +230,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         if not args.no_attack and world == 1:
-            line['extra'] = attack_gauss_bench(dev)
+            line['attack'] = attack_bench(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

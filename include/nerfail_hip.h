@@ -163,6 +163,21 @@ int nerfail_gauss_bwd(const float* weight_and_index, const float* ori_img, const
                       const float* grad_x, const float* grad_x_rgba, int64_t Ns, int64_t B, int64_t P,
                       float epsilon, float* grad_spatial, void* stream);
 
+/* Deterministic form of the same backward. The index map of a view is static, so its inverse (for each
+ * row of the perturbation table, the contributions (view b, pixel p, neighbour k) that gather from it, in
+ * ascending (b*P+p)*8+k order) is built once and reused by every attack epoch:
+ *   row_ptr[B*Ns+1] int32, contrib[B*P*8] int32 (contribution id), w_sorted[B*P*8] (its weight).
+ * workspace: nerfail_gauss_csr_workspace_bytes() bytes of scratch (0 = sizes unsupported). */
+size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64_t P);
+int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns, int64_t B, int64_t P, int32_t* row_ptr,
+                            int32_t* contrib, float* w_sorted, void* workspace, size_t workspace_bytes, void* stream);
+/* grad_spatial[Ns,4] = (accumulate ? grad_spatial : 0) + gather-reduce of the per-pixel gradient over the
+ * inverted index: no atomics, fixed summation order, bitwise reproducible. pixel_grad_scratch: B*P*4 floats. */
+int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
+                          const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns, int64_t B,
+                          int64_t P, float epsilon, float* pixel_grad_scratch, int accumulate, float* grad_spatial,
+                          void* stream);
+
 /* NeRFail-S sign step, AS:352-392: rgb <- rgb -/+ a*sign(grad) where alpha > 0 else 0, clamped to
  * init +- epsilon; alpha channel copied. spatial/grad/spatial_init/out are [n,4]; out may alias spatial. */
 int nerfail_igsm_step(const float* spatial, const float* grad, const float* spatial_init, int64_t n,

@@ -12,11 +12,51 @@ from . import _lib
 from .run_nerf_helpers import _cuda
 
 
+class GaussCSR:
+    """Inverted index of a batch of views' 8-NN maps (built once per batch tensor, reused by every backward):
+    row_ptr [B*Ns+1] int32, contrib [B*P*8] int32, w_sorted [B*P*8] float32 (nerfail_gauss_csr_build)."""
+
+    def __init__(self, wi, Ns):
+        lib = _lib.load()
+        B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
+        nbytes = lib.nerfail_gauss_csr_workspace_bytes(Ns, B, P)
+        if nbytes == 0:
+            raise ValueError('batch too large for the 32-bit inverted index (B*P*8 < 2^31, B*Ns < 2^32)')
+        dev = wi.device
+        self.Ns, self.B, self.P = Ns, B, P
+        self.row_ptr = torch.empty((B * Ns + 1,), dtype=torch.int32, device=dev)
+        self.contrib = torch.empty((B * P * 8,), dtype=torch.int32, device=dev)
+        self.w_sorted = torch.empty((B * P * 8,), dtype=torch.float32, device=dev)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.nerfail_gauss_csr_build(_lib.dev(wi), Ns, B, P, _lib.dev(self.row_ptr), _lib.dev(self.contrib),
+                                               _lib.dev(self.w_sorted), _lib.dev(ws), nbytes, _lib.stream()))
+        self._wi = wi          # keeps the map alive so its address cannot be recycled under the cache key
+
+
+_CSR_CACHE = {}
+CSR_CACHE_SIZE = 8
+
+
+def csr_for(wi, Ns):
+    """Identity-keyed LRU of inverted indices (index maps are static per view and repeat across epochs)."""
+    key = (wi.data_ptr(), wi._version, tuple(wi.shape), int(Ns))
+    hit = _CSR_CACHE.pop(key, None)
+    if hit is None:
+        hit = GaussCSR(wi, Ns)
+        while len(_CSR_CACHE) >= CSR_CACHE_SIZE:
+            _CSR_CACHE.pop(next(iter(_CSR_CACHE)))
+    _CSR_CACHE[key] = hit
+    return hit
+
+
 class _GaussGather(torch.autograd.Function):
-    """x, x_rgba = f(spatial_rgb); d/d(spatial_rgb) by nerfail_gauss_bwd. weight/index/ori carry no grad."""
+    """x, x_rgba = f(spatial_rgb); d/d(spatial_rgb) by the hand-written backward. weight/index/ori carry no grad.
+
+    deterministic=True : gather-reduce over the cached inverted index (no atomics, bitwise reproducible).
+    deterministic=False: scatter with float atomics (nerfail_gauss_bwd; no setup, order-dependent last bits)."""
 
     @staticmethod
-    def forward(ctx, spatial, wi, ori, epsilon, eps_minmax):
+    def forward(ctx, spatial, wi, ori, epsilon, eps_minmax, deterministic):
         dev = spatial.device
         s = _lib.f32c(spatial).reshape(-1, 4)
         B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
@@ -29,33 +69,45 @@ class _GaussGather(torch.autograd.Function):
         ctx.save_for_backward(wi, ori, x)
         ctx.eps = eps
         ctx.s_shape = tuple(spatial.shape)
+        ctx.deterministic = bool(deterministic)
         return x, x_rgba
 
     @staticmethod
     def backward(ctx, grad_x, grad_x_rgba):
         wi, ori, x = ctx.saved_tensors
+        lib = _lib.load()
         B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
         n = 1
         for d in ctx.s_shape[:-1]:
             n *= d
-        gs = torch.zeros((n, 4), dtype=torch.float32, device=x.device)
         gx = _lib.f32c(grad_x) if grad_x is not None else None
         gr = _lib.f32c(grad_x_rgba) if grad_x_rgba is not None else None
-        _lib.check(_lib.load().nerfail_gauss_bwd(_lib.dev(wi), _lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr),
-                                                 n, B, P, ctx.eps, _lib.dev(gs), _lib.stream()))
-        return gs.reshape(ctx.s_shape), None, None, None, None
+        if ctx.deterministic:
+            csr = csr_for(wi, n)
+            gs = torch.empty((n, 4), dtype=torch.float32, device=x.device)
+            scratch = torch.empty((B * P, 4), dtype=torch.float32, device=x.device)
+            _lib.check(lib.nerfail_gauss_bwd_csr(_lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr),
+                                                 _lib.dev(csr.row_ptr), _lib.dev(csr.contrib), _lib.dev(csr.w_sorted),
+                                                 n, B, P, ctx.eps, _lib.dev(scratch), 0, _lib.dev(gs), _lib.stream()))
+        else:
+            gs = torch.zeros((n, 4), dtype=torch.float32, device=x.device)
+            _lib.check(lib.nerfail_gauss_bwd(_lib.dev(wi), _lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr),
+                                             n, B, P, ctx.eps, _lib.dev(gs), _lib.stream()))
+        return gs.reshape(ctx.s_shape), None, None, None, None, None
 
 
-def gauss_gather(spatial_rgb, weight_and_index_list, ori_img, epsilon=None, eps_minmax=None):
+def gauss_gather(spatial_rgb, weight_and_index_list, ori_img, epsilon=None, eps_minmax=None, deterministic=True):
     """Functional form of the hot part: returns (x, x_rgba), differentiable w.r.t. spatial_rgb."""
     dev = _cuda()
-    wi = _lib.f32c(weight_and_index_list, dev)
+    wi = weight_and_index_list
+    if not (isinstance(wi, torch.Tensor) and wi.is_cuda and wi.dtype == torch.float32 and wi.is_contiguous()):
+        wi = _lib.f32c(wi, dev)          # (a tensor already resident keeps its identity -> inverted-index cache hit)
     ori = _lib.f32c(ori_img, dev)
     if wi.dim() != 5 or wi.shape[1] != 2 or wi.shape[4] != 8:
         raise ValueError('weight_and_index_list must be [B,2,H,W,8] (DW:95-97)')
     if spatial_rgb.device != dev:
         spatial_rgb = spatial_rgb.to(dev)
-    return _GaussGather.apply(spatial_rgb, wi, ori, epsilon, eps_minmax)
+    return _GaussGather.apply(spatial_rgb, wi, ori, epsilon, eps_minmax, deterministic)
 
 
 class gauss_net(nn.Module):
@@ -70,6 +122,7 @@ class gauss_net(nn.Module):
         self.model_name = model_name
         self.epsilon = epsilon
         self.update_epsilon_3d = True
+        self.deterministic = True    # backward = gather-reduce over a cached inverted index (False: float atomics)
         self._eps_minmax = None      # device-side running [min, max] of x_rgb*alpha (GN:89-103), read lazily
 
     # -- resize of the cold tail: torchvision if present (as the reference), else the same bilinear op in torch
@@ -110,7 +163,7 @@ class gauss_net(nn.Module):
     def forward(self, spatial_rgb, weight_and_index_list, ori_img, zero_init_mask: bool = False):
         ori_img = _lib.f32c(torch.as_tensor(ori_img), _cuda())           # GN:55
         x, x_rgba = gauss_gather(spatial_rgb, weight_and_index_list, ori_img, self.epsilon,
-                                 self._mm() if self.update_epsilon_3d else None)
+                                 self._mm() if self.update_epsilon_3d else None, self.deterministic)
         # ---- cold tail, GN:121-157 (stock PyTorch)
         cla_x = x_rgba.transpose(2, 3).transpose(1, 2)
         cla_ori_img = ori_img.transpose(2, 3).transpose(1, 2)

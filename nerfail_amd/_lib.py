@@ -55,6 +55,9 @@ SIGNATURES = {
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),
+    'nerfail_gauss_csr_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i64, c_i64]),
+    'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
     'nerfail_igsm_step': (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p]),
 }
 
@@ -95,7 +98,7 @@ def dev(t, name='tensor'):
         raise TypeError('%s must be a torch.Tensor' % name)
     if not t.is_cuda:
         raise RuntimeError('%s is on %s: nerfail_amd runs on the MI355X only (no CPU path)' % (name, t.device))
-    if t.dtype != torch.float32 and t.dtype != torch.int32:
+    if t.dtype not in (torch.float32, torch.int32, torch.uint8):
         raise TypeError('%s must be float32 (got %s)' % (name, t.dtype))
     if not t.is_contiguous():
         raise ValueError('%s must be contiguous' % name)

@@ -1,0 +1,180 @@
+// K11 deterministic form: the gather backward (autograd of model/GaussNet.py:63-83) as a gather-REDUCE
+// over an inverted index instead of a scatter with float atomics.
+//
+// The 8-NN index map of a view is static (it is built once by create_index_and_dist and reused by every
+// attack epoch), so its inverse - for each row j of the perturbation table, the list of (pixel, k) that
+// gather from it - is built once (radix sort of (destination, contribution id) pairs, rocPRIM via hipCUB)
+// and reused. The backward is then
+//     pass 1 (per pixel, streaming):  g[p] = dL/dx[p]  (chain through alpha / epsilon clip / where / clip)
+//     pass 2 (per destination row):   grad_s[j] = sum_{c in row j} w_c * g[pixel_c]     in a FIXED order
+// => bitwise reproducible, no atomics (the MI355X float-atomic rate for 16-byte scattered segments is
+// ~0.08 TB/s; the gathers here are served by L2 / Infinity Cache).
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace nerfail {
+
+__global__ __launch_bounds__(256) void csr_keys_kernel(const float* __restrict__ wi, long Ns, long B, long P,
+                                                       unsigned* __restrict__ keys, int* __restrict__ vals) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;     // contribution id = (b*P + p)*8 + k
+    if (g >= B * P * 8) return;
+    const long bp = g >> 3;
+    const int k = (int)(g & 7);
+    const long b = bp / P, p = bp - b * P;
+    long j = (long)wi[((b * 2 + 1) * P + p) * 8 + k];
+    j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
+    keys[g] = (unsigned)(b * Ns + j);
+    vals[g] = (int)g;
+}
+
+// row_ptr[r] = first sorted position whose key >= r (r in [0, B*Ns]); weights gathered into sorted order
+__global__ __launch_bounds__(256) void csr_rows_kernel(const unsigned* __restrict__ keys_sorted, long n, long rows,
+                                                       int* __restrict__ row_ptr) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    long lo = 0, hi = n;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if ((long)keys_sorted[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    row_ptr[r] = (int)lo;
+}
+
+__global__ __launch_bounds__(256) void csr_weights_kernel(const float* __restrict__ wi, const int* __restrict__ contrib,
+                                                          long n, long P, float* __restrict__ w_sorted) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const long g = contrib[c];
+    const long bp = g >> 3;
+    const long b = bp / P, p = bp - b * P;
+    w_sorted[c] = wi[((b * 2 + 0) * P + p) * 8 + (g & 7)];
+}
+
+// pass 1: effective dL/dx per pixel (same chain as gauss_bwd_kernel in gauss.hip)
+__global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __restrict__ ori, const float4* __restrict__ x_saved,
+                                                               const float4* __restrict__ grad_x,
+                                                               const float4* __restrict__ grad_x_rgba, long n, float epsilon,
+                                                               float4* __restrict__ g_out) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const float4 x = x_saved[g];
+    const float4 o = ori[g];
+    float4 gx = (grad_x != nullptr) ? grad_x[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grad_x_rgba != nullptr && o.w > 0.f) {
+        const float4 gr = grad_x_rgba[g];
+        const float alpha = x.w / 255.0f;
+        const float xc[3] = {x.x, x.y, x.z}, oc[3] = {o.x, o.y, o.z}, grc[3] = {gr.x, gr.y, gr.z};
+        float gxc[3] = {0.f, 0.f, 0.f};
+        float ga = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = xc[c] * alpha;
+            bool pass = true;
+            if (epsilon >= 0.f) {
+                pass = (d >= -epsilon) && (d <= epsilon);
+                d = fminf(fmaxf(d, -epsilon), epsilon);
+            }
+            const float pre = oc[c] + d;
+            pass = pass && (pre >= 0.f) && (pre <= 255.f);
+            const float gd = pass ? grc[c] : 0.f;
+            gxc[c] = gd * alpha;
+            ga += gd * xc[c];
+        }
+        gx.x += gxc[0]; gx.y += gxc[1]; gx.z += gxc[2];
+        gx.w += ga / 255.0f;
+    }
+    g_out[g] = gx;
+}
+
+// pass 2: one thread per destination row; views in ascending order, contributions in ascending id order
+__global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __restrict__ row_ptr, const int* __restrict__ contrib,
+                                                               const float* __restrict__ w_sorted,
+                                                               const float4* __restrict__ g_pix, long Ns, long B,
+                                                               int accumulate, float4* __restrict__ grad_spatial) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ns) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long b = 0; b < B; ++b) {
+        const int c0 = row_ptr[b * Ns + j], c1 = row_ptr[b * Ns + j + 1];
+        for (int c = c0; c < c1; ++c) {
+            const float w = w_sorted[c];
+            const float4 g = g_pix[contrib[c] >> 3];
+            acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+        }
+    }
+    if (accumulate) {
+        const float4 old = grad_spatial[j];
+        acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+    }
+    grad_spatial[j] = acc;
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t cub_temp_bytes(long n) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+                                       (int*)nullptr, (int)n, 0, 32, (hipStream_t) nullptr);
+    return bytes;
+}
+
+}  // namespace nerfail
+
+using namespace nerfail;
+
+extern "C" size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64_t P) {
+    if (Ns <= 0 || B <= 0 || P <= 0) return 0;
+    const long n = B * P * 8;
+    if (n >= (1L << 31) || B * Ns >= (1L << 32) - 1) return 0;
+    return 3 * align256((size_t)n * 4) + align256(cub_temp_bytes(n));
+}
+
+extern "C" int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns, int64_t B, int64_t P, int32_t* row_ptr,
+                                       int32_t* contrib, float* w_sorted, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    NF_REQUIRE(Ns > 0 && B > 0 && P > 0, "bad sizes");
+    const long n = B * P * 8;
+    NF_REQUIRE(n < (1L << 31) && B * Ns < (1L << 32) - 1, "batch too large for 32-bit CSR ids");
+    NF_REQUIRE(weight_and_index && row_ptr && contrib && w_sorted && workspace, "NULL pointer");
+    const size_t need = nerfail_gauss_csr_workspace_bytes(Ns, B, P);
+    NF_REQUIRE(workspace_bytes >= need, "workspace too small (nerfail_gauss_csr_workspace_bytes)");
+    hipStream_t s = as_stream(stream);
+    char* ws = (char*)workspace;
+    const size_t seg = align256((size_t)n * 4);
+    unsigned* keys_in = (unsigned*)ws;
+    unsigned* keys_out = (unsigned*)(ws + seg);
+    int* vals_in = (int*)(ws + 2 * seg);
+    void* temp = ws + 3 * seg;
+    size_t temp_bytes = workspace_bytes - 3 * seg;
+    csr_keys_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(weight_and_index, Ns, B, P, keys_in, vals_in);
+    NF_LAUNCHED("csr_keys_kernel");
+    int bits = 1;
+    while ((1L << bits) < B * Ns + 1) ++bits;     // sort only the significant key bits (stable LSD radix)
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, contrib, (int)n, 0, bits, s);
+    if (e != hipSuccess) return hip_fail(e, "hipcub::DeviceRadixSort::SortPairs");
+    const long rows = B * Ns;
+    csr_rows_kernel<<<dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, s>>>(keys_out, n, rows, row_ptr);
+    NF_LAUNCHED("csr_rows_kernel");
+    csr_weights_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(weight_and_index, contrib, n, P, w_sorted);
+    NF_LAUNCHED("csr_weights_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
+                                     const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns,
+                                     int64_t B, int64_t P, float epsilon, float* pixel_grad_scratch, int accumulate,
+                                     float* grad_spatial, void* stream) {
+    NF_REQUIRE(Ns > 0 && B > 0 && P > 0, "bad sizes");
+    NF_REQUIRE(ori_img && x && row_ptr && contrib && w_sorted && pixel_grad_scratch && grad_spatial, "NULL pointer");
+    hipStream_t s = as_stream(stream);
+    const long n = B * P;
+    gauss_pixel_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x, (const float4*)grad_x_rgba, n, epsilon,
+        (float4*)pixel_grad_scratch);
+    NF_LAUNCHED("gauss_pixel_grad_kernel");
+    gauss_row_reduce_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(
+        row_ptr, contrib, w_sorted, (const float4*)pixel_grad_scratch, Ns, B, accumulate, (float4*)grad_spatial);
+    NF_LAUNCHED("gauss_row_reduce_kernel");
+    return NERFAIL_OK;
+}

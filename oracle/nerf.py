@@ -218,3 +218,107 @@ def render(H, W, K, c2w, near, far, sd_coarse, sd_fine, N_samples=64, N_importan
         outs.append(render_rays(rays[s:s + chunk], sd_coarse, N_samples, N_importance, sd_fine,
                                 white_bkgd, D=D, W=Wn))
     return {k: np.concatenate([o[k] for o in outs], 0) for k in outs[0]}
+
+
+# ----------------------------------------------------------------------------- training step (fwd + bwd)
+def _mlp_forward_cached(sd, pts, viewdirs, D, W, skips=(4,)):
+    R, N = pts.shape[:2]
+    flat = pts.reshape(-1, 3)
+    dirs = np.broadcast_to(np.asarray(viewdirs, F32)[:, None, :], pts.shape).reshape(-1, 3)
+    e_p, e_d = embed(flat, 10), embed(dirs, 4)
+    ins, pre = [], []
+    h = e_p
+    for i in range(D):
+        ins.append(h)
+        z = h @ sd['pts_linears.%d.weight' % i].T + sd['pts_linears.%d.bias' % i]
+        pre.append(z)
+        h = np.maximum(z, F32(0))
+        if i in skips and i < D - 1:
+            h = np.concatenate([e_p, h], -1)
+    alpha = h @ sd['alpha_linear.weight'].T + sd['alpha_linear.bias']
+    feature = h @ sd['feature_linear.weight'].T + sd['feature_linear.bias']
+    hv_in = np.concatenate([feature, e_d], -1)
+    hv_pre = hv_in @ sd['views_linears.0.weight'].T + sd['views_linears.0.bias']
+    hv = np.maximum(hv_pre, F32(0))
+    rgb = hv @ sd['rgb_linear.weight'].T + sd['rgb_linear.bias']
+    raw = np.concatenate([rgb, alpha], -1).astype(F32)
+    return raw.reshape(R, N, 4), dict(ins=ins, pre=pre, h_last=h, hv_in=hv_in, hv_pre=hv_pre, hv=hv)
+
+
+def mlp_backward(sd, cache, d_raw, D, W, skips=(4,)):
+    """Gradients of all NeRF parameters given d_raw [M,4] (autograd of RH:100-123); float64 accumulation."""
+    f8 = np.float64
+    d_raw = np.asarray(d_raw, f8).reshape(-1, 4)
+    g = {}
+    d_rgb, d_alpha = d_raw[:, :3], d_raw[:, 3:4]
+    g['rgb_linear.weight'] = d_rgb.T @ cache['hv'].astype(f8)
+    g['rgb_linear.bias'] = d_rgb.sum(0)
+    d_hv = (d_rgb @ sd['rgb_linear.weight'].astype(f8)) * (cache['hv_pre'] > 0)
+    g['views_linears.0.weight'] = d_hv.T @ cache['hv_in'].astype(f8)
+    g['views_linears.0.bias'] = d_hv.sum(0)
+    d_feat = (d_hv @ sd['views_linears.0.weight'].astype(f8))[:, :W]
+    h = cache['h_last'].astype(f8)
+    g['feature_linear.weight'] = d_feat.T @ h
+    g['feature_linear.bias'] = d_feat.sum(0)
+    g['alpha_linear.weight'] = d_alpha.T @ h
+    g['alpha_linear.bias'] = d_alpha.sum(0)
+    d_h = d_feat @ sd['feature_linear.weight'].astype(f8) + d_alpha @ sd['alpha_linear.weight'].astype(f8)
+    for i in reversed(range(D)):
+        if i in skips and i < D - 1:
+            d_h = d_h[:, 63:]                     # the concatenated input_pts part carries no parameters
+        d_z = d_h * (cache['pre'][i] > 0)
+        g['pts_linears.%d.weight' % i] = d_z.T @ cache['ins'][i].astype(f8)
+        g['pts_linears.%d.bias' % i] = d_z.sum(0)
+        d_h = d_z @ sd['pts_linears.%d.weight' % i].astype(f8)
+    return {k: v.astype(F32) for k, v in g.items()}
+
+
+def raw2outputs_backward(raw, z_vals, rays_d, d_rgb_map, white_bkgd=True):
+    """d(loss)/d(raw) for a loss that depends on rgb_map only (RN:781-789); autograd of RN:262-305."""
+    f8 = np.float64
+    raw = np.asarray(raw, F32)
+    z_vals = np.asarray(z_vals, F32)
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = np.concatenate([dists, np.full_like(dists[..., :1], 1e10)], -1)
+    nrm = np.sqrt((np.asarray(rays_d, F32) ** 2).sum(-1, dtype=F32)).astype(F32)
+    dists = (dists * nrm[..., None]).astype(f8)
+    c = 1.0 / (1.0 + np.exp(-raw[..., :3].astype(f8)))
+    sig = raw[..., 3].astype(f8)
+    with np.errstate(over='ignore'):
+        e = np.exp(-np.maximum(sig, 0.0) * dists)
+    alpha = (F32(1) - e.astype(F32)).astype(f8)                       # forward values are float32
+    t = (1.0 - alpha) + 1e-10
+    T = np.concatenate([np.ones_like(alpha[..., :1]), np.cumprod(t, -1)[..., :-1]], -1)
+    w = alpha * T
+    g = np.asarray(d_rgb_map, f8)[:, None, :]                         # [R,1,3]
+    gw = (g * c).sum(-1) - (g.sum(-1) if white_bkgd else 0.0)        # dL/dw_i
+    gwW = gw * w
+    S = np.flip(np.cumsum(np.flip(gwW, -1), -1), -1) - gwW            # sum_{k>i} gw_k w_k
+    d_alpha = gw * T - S / t
+    d_sigma = d_alpha * dists * (1.0 - alpha) * (sig > 0)
+    d_rgbraw = (w[..., None] * g) * c * (1.0 - c)
+    return np.concatenate([d_rgbraw, d_sigma[..., None]], -1).astype(F32)
+
+
+def train_step_grads(ray_batch, sd_coarse, sd_fine, target, N_samples=64, N_importance=128, t_rand=None, u=None,
+                     D=8, W=256, white_bkgd=True):
+    """One training step's loss and parameter gradients (RN:776-791): loss = mse(rgb, t) + mse(rgb0, t)."""
+    ray_batch = np.asarray(ray_batch, F32)
+    rays_o, rays_d, viewdirs = ray_batch[:, 0:3], ray_batch[:, 3:6], ray_batch[:, -3:]
+    z0 = coarse_z_vals(ray_batch[:, 6:7], ray_batch[:, 7:8], N_samples, t_rand)
+    pts0 = (rays_o[:, None, :] + rays_d[:, None, :] * z0[:, :, None]).astype(F32)
+    raw0, cache0 = _mlp_forward_cached(sd_coarse, pts0, viewdirs, D, W)
+    rgb0, _, _, w0, _ = raw2outputs(raw0, z0, rays_d, None, white_bkgd)
+    z_mid = F32(.5) * (z0[..., 1:] + z0[..., :-1])
+    z_s = sample_pdf(z_mid, w0[..., 1:-1], N_importance, u=u)
+    z1 = np.sort(np.concatenate([z0, z_s], -1), -1)
+    pts1 = (rays_o[:, None, :] + rays_d[:, None, :] * z1[:, :, None]).astype(F32)
+    raw1, cache1 = _mlp_forward_cached(sd_fine, pts1, viewdirs, D, W)
+    rgb1, _, _, _, _ = raw2outputs(raw1, z1, rays_d, None, white_bkgd)
+    target = np.asarray(target, F32)
+    loss = float(np.mean((rgb1 - target) ** 2, dtype=np.float64) + np.mean((rgb0 - target) ** 2, dtype=np.float64))
+    n = rgb1.size
+    d1 = raw2outputs_backward(raw1, z1, rays_d, 2.0 * (rgb1 - target) / n, white_bkgd)
+    d0 = raw2outputs_backward(raw0, z0, rays_d, 2.0 * (rgb0 - target) / n, white_bkgd)
+    return dict(loss=loss, rgb_map=rgb1, rgb0=rgb0, d_raw_fine=d1, d_raw_coarse=d0,
+                grads_fine=mlp_backward(sd_fine, cache1, d1, D, W), grads_coarse=mlp_backward(sd_coarse, cache0, d0, D, W))

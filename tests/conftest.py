@@ -39,3 +39,11 @@ def rel_err(a, b, floor=1e-6):
         return 0.0
     scale = np.maximum(np.abs(b[m]), floor + 1e-3 * np.abs(b[m]).max())
     return float((np.abs(a[m] - b[m]) / scale).max())
+
+
+def l2_err(a, b):
+    """||a-b|| / ||b|| over the whole tensor (float64): the measure used for parameter gradients."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

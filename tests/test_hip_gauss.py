@@ -21,13 +21,14 @@ def test_create_gauss_w(golden):
     assert (N(i_w)[0, 0, 0, 0] == 0).all()
 
 
+@pytest.mark.parametrize('det', [True, False])
 @pytest.mark.parametrize('tag,eps', [('epsNone_', None), ('eps32_', 32.0)])
-def test_gauss_forward_backward(golden, tag, eps):
+def test_gauss_forward_backward(golden, tag, eps, det):
     from nerfail_amd.GaussNet import gauss_gather
     g = golden('g10_gauss_net')
     s = T(g['s']).requires_grad_(True)
     mm = torch.zeros(2, device=dev())
-    x, x_rgba = gauss_gather(s, T(g['wi']), T(g['ori']), eps, mm)
+    x, x_rgba = gauss_gather(s, T(g['wi']), T(g['ori']), eps, mm, deterministic=det)
     assert rel_err(N(x), g[tag + 'x']) < 1e-5
     assert rel_err(N(x_rgba), g[tag + 'x_rgba']) < 1e-5
     assert abs(float(mm[1]) - float(g[tag + 'eps3d_max'])) < 1e-3 * abs(float(mm[1]))
@@ -85,6 +86,15 @@ def test_gauss_full_size_properties():
     s = s1.clone().requires_grad_(True)
     x, _ = gauss_gather(s, wi, ori, None)
     (x * G).sum().backward()
+    # deterministic (inverted-index) backward: bitwise reproducible, and equal to the atomic form to rounding
+    s_b = s1.clone().requires_grad_(True)
+    xb, _ = gauss_gather(s_b, wi, ori, None)
+    (xb * G).sum().backward()
+    assert torch.equal(s.grad, s_b.grad)
+    s_c = s1.clone().requires_grad_(True)
+    xc, _ = gauss_gather(s_c, wi, ori, None, deterministic=False)
+    (xc * G).sum().backward()
+    assert rel_err(N(s_c.grad), N(s.grad)) < 1e-4
     lhs = float((x2.double() * G.double()).sum())
     rhs = float((s.grad.double() * s2.double()).sum())
     assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), abs(rhs), 1.0) * 10
