@@ -71,6 +71,53 @@ def cpu_baseline(seconds_budget=20.0):
                       '(oracle/nerf.py, OpenBLAS sgemm on all host cores), %.1f s' % (n, dt)}
 
 
+def train_bench(dev, steps=10, warmup=2, n_rand=1024):
+    """NeRF training step (RN:776-801) at the shipped config (configs/lego.txt: N_rand=1024, 64+128 samples,
+    D=8 W=256, perturb=1, white_bkgd): render -> mse(rgb)+mse(rgb0) -> backward -> Adam. rays/s (fwd+bwd)."""
+    from nerfail_amd import run_nerf as RN
+    from nerfail_amd.run_nerf import ray_gen
+    _, coarse = make_net(31, dev)
+    _, fine = make_net(32, dev)
+    params = list(coarse.parameters()) + list(fine.parameters())
+    for p in params:
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    focal, K = synth.lego_intrinsics(H, W)
+    c2w = synth.pose_spherical(-180., -30., 4.)[:3, :4]
+    all_rays = ray_gen(H, W, K, c2w, 2., 6.)
+    rs = np.random.RandomState(0)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    ev = []
+
+    def step():
+        sel = torch.from_numpy(rs.choice(H * W, size=[n_rand], replace=False)).to(dev)      # RN:768
+        rays = all_rays[sel].contiguous()
+        target = torch.rand((n_rand, 3), device=dev, generator=gen)
+        t_rand = torch.rand((n_rand, N_SAMPLES), device=dev, generator=gen)
+        u = torch.rand((n_rand, N_IMPORTANCE), device=dev, generator=gen)
+        r = RN.render_rays(rays, coarse, None, N_SAMPLES, N_importance=N_IMPORTANCE, network_fine=fine, white_bkgd=True,
+                           perturb=1., t_rand=t_rand, u=u)
+        loss = RN.img2mse(r['rgb_map'], target) + RN.img2mse(r['rgb0'], target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / steps
+    flop = n_rand * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_PER_SAMPLE * 3     # fwd + bwd-data + bwd-weights
+    return {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand,
+            'final_loss': float(loss.detach()),
+            'roofline': {'bound': 'mfma', 'achieved': flop / dt / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': flop / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'note': 'whole step incl. sampling, compositing, Adam and host launch gaps; 3x forward FLOPs'}}
+
+
 def victim_cnn(num_classes=8):
     """Stand-in victim with the shape of the reference's 800x800 classifier (model/MyModel.py:5-52: seven
     3x3 conv + ReLU + 2x2 max-pool stages 3-32-64-128-256-256-128-64, then 1024-512-classes). Stock PyTorch
@@ -128,7 +175,9 @@ def attack_bench(dev, iters=5):
                          'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
 
     torch.manual_seed(0)
-    net = gauss_net(dev, 0.02, victim_cnn(8).to(dev), 'my_model', epsilon=None)
+    victim = victim_cnn(8).to(dev)
+    victim.requires_grad_(False)                   # the attack differentiates w.r.t. the perturbation only
+    net = gauss_net(dev, 0.02, victim, 'my_model', epsilon=None)
     label = torch.tensor(4, device=dev)
     dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
     out['end_to_end_victim_cnn'] = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
@@ -191,12 +240,14 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
+        with torch.no_grad():
+            step(i)
     barrier()
     mlp_events.clear()
     t0 = time.time()
     for i in range(args.steps):
-        out = step(args.warmup + i)
+        with torch.no_grad():                      # render-only, as nerf_to_coord.py:619 does
+            out = step(args.warmup + i)
     barrier()
     elapsed = time.time() - t0
     if world > 1:
@@ -230,6 +281,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         if not args.no_attack and world == 1:
+            line['train'] = train_bench(dev)
             line['attack'] = attack_bench(dev)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -122,6 +122,25 @@ int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, const float* pt
 int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int skip, const float* x, int64_t M,
                              float* raw, void* stream);
 
+/* ---- training step (RN:776-801): forward that saves activations, backward-data, weight gradients -------- */
+
+/* Floats of the activation / gradient scratch of one pass over M samples (0 = unsupported shape). */
+size_t nerfail_mlp_train_acts_floats(int D, int W, int64_t M);
+size_t nerfail_mlp_train_dz_floats(int D, int W, int64_t M);
+/* nerfail_mlp_fwd that additionally writes every layer's activation to `acts` (register-fragment layout). */
+int nerfail_mlp_fwd_train(const float* packed, int D, int W, int skip, const float* pts, const float* viewdirs,
+                          int64_t M, int samples_per_ray, float* raw, float* acts, void* stream);
+/* Transposed weight image for the backward-data pass (re-pack after every optimizer step). */
+size_t nerfail_mlp_packed_T_floats(int D, int W, int skip);
+int nerfail_mlp_pack_T(const nerfail_mlp_params* params_host, float* packedT, void* stream);
+/* d_raw[M,4] -> gradient w.r.t. every layer's pre-activation (`dz`, fragment layout). */
+int nerfail_mlp_bwd_data(const float* packed, const float* packedT, int D, int W, int skip, const float* d_raw,
+                         const float* acts, int64_t M, float* dz, void* stream);
+/* Parameter gradients: grads_host holds DEVICE pointers shaped like the nn.Linear tensors (same struct as the
+ * weights); every gradient is ACCUMULATED into (+=, float atomics), so zero them for a fresh gradient. */
+int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
+                            const nerfail_mlp_params* grads_host, void* stream);
+
 /* ------------------------------------------------------------------ compositing (K5, K7) -- */
 
 /* raw2outputs, RN:262-305, one wavefront per ray with a wave-level exclusive product scan.
@@ -132,6 +151,14 @@ int nerfail_composite(const float* raw, const float* z_vals, const float* rays, 
                       int64_t n_rays, int n_samples, int white_bkgd,
                       float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
                       const float* pts, float* pts_max, void* stream);
+
+/* Backward of raw2outputs (autograd of RN:262-305, what loss.backward() at RN:791 needs): given the upstream
+ * gradients of rgb_map[R,3], disp_map[R], acc_map[R], depth_map[R], weights[R,N] (each may be NULL = zero)
+ * writes d_raw[R,N,4]. z_vals / rays_d receive no gradient (z_samples is detached, RN:394). */
+int nerfail_composite_bwd(const float* raw, const float* z_vals, const float* rays, const float* noise,
+                          int64_t n_rays, int n_samples, int white_bkgd, const float* g_rgb_map,
+                          const float* g_disp_map, const float* g_acc_map, const float* g_depth_map,
+                          const float* g_weights, float* d_raw, void* stream);
 
 /* ------------------------------------------------------------------ 8-NN build (K8) ------- */
 

@@ -50,7 +50,15 @@ SIGNATURES = {
     'nerfail_mlp_pack': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
     'nerfail_mlp_fwd': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
     'nerfail_mlp_fwd_embedded': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p]),
+    'nerfail_mlp_train_acts_floats': (ctypes.c_size_t, [c_i, c_i, c_i64]),
+    'nerfail_mlp_train_dz_floats': (ctypes.c_size_t, [c_i, c_i, c_i64]),
+    'nerfail_mlp_fwd_train': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
+    'nerfail_mlp_packed_T_floats': (ctypes.c_size_t, [c_i, c_i, c_i]),
+    'nerfail_mlp_pack_T': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
+    'nerfail_mlp_bwd_data': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
+    'nerfail_mlp_bwd_weights': (c_i, [c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.POINTER(MlpParams), c_p]),
     'nerfail_composite': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'nerfail_composite_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_knn8': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),

@@ -1,0 +1,147 @@
+// K5b: backward of raw2outputs (run_nerf.py:262-305), i.e. what loss.backward() (RN:791) pushes into `raw`.
+//
+// One wavefront per ray, same sample->lane mapping as the forward (lane owns IPL consecutive samples). The
+// forward quantities (alpha, exp term, transmittance, weights, sigmoid colours) are recomputed, then
+//     gw_i      = dL/dw_i = <g_rgb, c_i> - [white_bkgd] sum(g_rgb) + g_acc + g_depth * z_i + g_weights_i
+//     dL/dalpha = gw_i * T_i - (sum_{k>i} gw_k w_k) / (1 - alpha_i + 1e-10)         (cumprod backward)
+//     dL/dsigma = dL/dalpha * dist_i * exp(-sigma_i dist_i) * [sigma_i > 0]
+//     dL/draw_c = w_i * g_rgb_c * c (1 - c)
+// with the suffix sum as a reverse 64-lane shuffle scan. g_disp is folded into g_depth / g_acc through
+// disp = 1/max(1e-10, depth/acc). HBM-bound: reads 20N+..., writes 16N bytes per ray.
+#include "common.h"
+
+namespace nerfail {
+
+// inclusive suffix sum across lanes: out[l] = sum_{m >= l} v[m]
+__device__ __forceinline__ float wave_suffix_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += t;
+    }
+    return v;
+}
+
+template <int IPL>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float4* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays,
+    const float* __restrict__ noise, long n_rays, int N, int white_bkgd,
+    const float* __restrict__ g_rgb, const float* __restrict__ g_disp, const float* __restrict__ g_acc,
+    const float* __restrict__ g_depth, const float* __restrict__ g_weights, float4* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float* rr = rays + NERFAIL_RAY_FLOATS * ray;
+    const float dx = rr[3], dy = rr[4], dz = rr[5];
+    const float nrm = sqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const long base = ray * N;
+    const int i0 = lane * IPL;
+
+    float z[IPL + 1], alpha[IPL], ex[IPL], dist[IPL], sig[IPL], cr[IPL], cg[IPL], cb[IPL], tt[IPL];
+#pragma unroll
+    for (int k = 0; k <= IPL; ++k) z[k] = (i0 + k < N) ? z_vals[base + i0 + k] : 0.0f;
+    float tprod = 1.0f;
+#pragma unroll
+    for (int k = 0; k < IPL; ++k) {
+        const int i = i0 + k;
+        alpha[k] = 0.f; ex[k] = 1.f; dist[k] = 0.f; sig[k] = 0.f; cr[k] = cg[k] = cb[k] = 0.f; tt[k] = 1.f;
+        if (i < N) {
+            const float4 rw = raw[base + i];
+            float d = (i < N - 1) ? __fsub_rn(z[k + 1], z[k]) : 1e10f;
+            d = __fmul_rn(d, nrm);
+            float s = rw.w;
+            if (noise != nullptr) s = __fadd_rn(s, noise[base + i]);
+            sig[k] = s;
+            dist[k] = d;
+            ex[k] = expf(-__fmul_rn(fmaxf(s, 0.f), d));
+            alpha[k] = __fsub_rn(1.0f, ex[k]);
+            cr[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.x)));
+            cg[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.y)));
+            cb[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.z)));
+            tt[k] = __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f);
+            tprod = __fmul_rn(tprod, tt[k]);
+        }
+    }
+    const float incl = wave_scan_mul(tprod, lane);
+    float T0 = __shfl_up(incl, 1, 64);
+    if (lane == 0) T0 = 1.0f;
+
+    float gr = 0.f, gg = 0.f, gb = 0.f;
+    if (g_rgb != nullptr) { gr = g_rgb[3 * ray]; gg = g_rgb[3 * ray + 1]; gb = g_rgb[3 * ray + 2]; }
+    float ga = (g_acc != nullptr) ? g_acc[ray] : 0.f;
+    float gd = (g_depth != nullptr) ? g_depth[ray] : 0.f;
+    if (white_bkgd) ga -= (gr + gg + gb);                  // rgb_map += 1 - acc
+    float T[IPL], w[IPL];
+    {
+        float Tk = T0, sd = 0.f, sa = 0.f;
+#pragma unroll
+        for (int k = 0; k < IPL; ++k) {
+            T[k] = Tk;
+            w[k] = __fmul_rn(alpha[k], Tk);
+            if (i0 + k < N) { sd += w[k] * z[k]; sa += w[k]; }
+            Tk = __fmul_rn(Tk, tt[k]);
+        }
+        if (g_disp != nullptr) {                           // disp = 1 / max(1e-10, depth / acc)
+            sd = wave_sum(sd); sa = wave_sum(sa);
+            const float ratio = sd / sa;
+            if (ratio > 1e-10f) {                          // false for NaN and for the clamped branch
+                const float gratio = -g_disp[ray] / (ratio * ratio);
+                gd += gratio / sa;
+                ga -= gratio * sd / (sa * sa);
+            }
+        }
+    }
+    float gw[IPL], gww = 0.f;
+#pragma unroll
+    for (int k = 0; k < IPL; ++k) {
+        gw[k] = 0.f;
+        if (i0 + k < N) {
+            gw[k] = gr * cr[k] + gg * cg[k] + gb * cb[k] + ga + gd * z[k];
+            if (g_weights != nullptr) gw[k] += g_weights[base + i0 + k];
+            gww += gw[k] * w[k];
+        }
+    }
+    // S for this lane's LAST sample = sum over later lanes; walk backwards inside the lane
+    const float suffix_incl = wave_suffix_sum(gww, lane);
+    float S = suffix_incl - gww;                           // contributions of lanes > this one
+#pragma unroll
+    for (int k = IPL - 1; k >= 0; --k) {
+        const int i = i0 + k;
+        if (i < N) {
+            const float dalpha = gw[k] * T[k] - S / tt[k];
+            const float dsig = (sig[k] > 0.f) ? dalpha * dist[k] * ex[k] : 0.f;
+            d_raw[base + i] = make_float4(w[k] * gr * cr[k] * (1.f - cr[k]), w[k] * gg * cg[k] * (1.f - cg[k]),
+                                          w[k] * gb * cb[k] * (1.f - cb[k]), dsig);
+            S += gw[k] * w[k];
+        }
+    }
+}
+
+}  // namespace nerfail
+
+using namespace nerfail;
+
+extern "C" int nerfail_composite_bwd(const float* raw, const float* z_vals, const float* rays, const float* noise,
+                                     int64_t n_rays, int n_samples, int white_bkgd, const float* g_rgb_map,
+                                     const float* g_disp_map, const float* g_acc_map, const float* g_depth_map,
+                                     const float* g_weights, float* d_raw, void* stream) {
+    NF_REQUIRE(n_rays >= 0, "n_rays is negative");
+    NF_REQUIRE(n_samples >= 2 && n_samples <= 256, "n_samples must be in [2, 256]");
+    if (n_rays == 0) return NERFAIL_OK;
+    NF_REQUIRE(raw != nullptr && z_vals != nullptr && rays != nullptr && d_raw != nullptr, "NULL pointer");
+    const dim3 block(256), grid((unsigned)((n_rays + 3) / 4));
+    hipStream_t s = as_stream(stream);
+#define NF_CB(IPL)                                                                                                  \
+    composite_bwd_kernel<IPL><<<grid, block, 0, s>>>((const float4*)raw, z_vals, rays, noise, n_rays, n_samples,     \
+                                                     white_bkgd, g_rgb_map, g_disp_map, g_acc_map, g_depth_map,      \
+                                                     g_weights, (float4*)d_raw)
+    switch ((n_samples + 63) / 64) {
+        case 1: NF_CB(1); break;
+        case 2: NF_CB(2); break;
+        case 3: NF_CB(3); break;
+        default: NF_CB(4); break;
+    }
+#undef NF_CB
+    NF_LAUNCHED("composite_bwd_kernel");
+    return NERFAIL_OK;
+}

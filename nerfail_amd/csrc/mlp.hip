@@ -21,58 +21,9 @@
 //   * alpha_linear (W->1) and rgb_linear (W/2->3) are too thin for a 32-wide MFMA tile: VALU dot
 //     products on the accumulator registers + one cross-half shuffle.
 // Bound: f32 MFMA (157 TFLOP/s dense on MI355X); algorithmic work 1 186 816 FLOP per sample (D8 W256).
-#include "common.h"
+#include "mlp_layout.h"
 
 namespace nerfail {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kPtsCh = 63, kDirCh = 27;
-constexpr int kEmbQuads = 8;   // 32 k-steps: 30 sin/cos pairs + (x|y) + (z|pad)
-constexpr int kDirQuads = 4;   // 16 k-steps: 12 sin/cos pairs + (x|y) + (z|pad) + 2 zero steps
-
-// Input channel of a positional encoding (RH:47-50 order: x(3), then per band sin(3), cos(3))
-// consumed by k-step s in lane half h; -1 = zero padding. `bands` = 10 (pts) or 4 (dirs).
-__host__ __device__ inline int enc_channel(int s, int h, int bands) {
-    if (s < 3 * bands) return 3 + 6 * (s / 3) + 3 * h + (s % 3);
-    if (s == 3 * bands) return h;               // x | y
-    if (s == 3 * bands + 1) return h ? -1 : 2;  // z | pad
-    return -1;
-}
-// Channel of a 32-channel accumulator tile held in register r of lane half h (32x32 C/D layout).
-__host__ __device__ inline int acc_channel(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-struct MlpLayout {
-    int NT, D, skip;
-    unsigned w_off[NERFAIL_MAX_DEPTH + 2];   // [0..D-1] pts layers, [D] feature, [D+1] views
-    unsigned b_off[NERFAIL_MAX_DEPTH + 2];
-    unsigned alpha_off, rgb_off, total;
-};
-
-static inline bool layer_has_emb(int l, int skip) { return l == 0 || (skip >= 0 && l == skip + 1); }
-
-static bool make_layout(int D, int W, int skip, MlpLayout& L) {
-    if (!(W == 64 || W == 128 || W == 256)) return false;
-    if (D < 2 || D > NERFAIL_MAX_DEPTH) return false;
-    if (skip >= D - 1) skip = -1;    // `if i in skips` never fires for the last layer's successor (RH:106)
-    L.NT = W / 32; L.D = D; L.skip = skip;
-    const int NT = L.NT, OTV = NT / 2;
-    unsigned off = 0;
-    for (int l = 0; l <= D + 1; ++l) {
-        const int OT = (l == D + 1) ? OTV : NT;
-        int quads = 0;
-        if (l <= D - 1 && layer_has_emb(l, skip)) quads += kEmbQuads;
-        if (l > 0) quads += NT * 4;
-        if (l == D + 1) quads += kDirQuads;
-        L.w_off[l] = off; off += (unsigned)quads * OT * 256;
-        L.b_off[l] = off; off += (unsigned)OT * 32;
-    }
-    L.alpha_off = off; off += (unsigned)NT * 32 + 4;
-    L.rgb_off = off; off += 3u * OTV * 32 + 4;
-    L.total = off;
-    return true;
-}
 
 // ------------------------------------------------------------------------------------- packing
 // One launch per MFMA layer: writes the A-fragment image [quad][tile][lane][4] and the bias image.
@@ -134,73 +85,13 @@ struct MlpArgs {
     const float* viewdirs;   // [rays,3]
     const float* xemb;       // [M,90] already embedded input, or NULL
     float* raw;              // [M,4]
+    float* acts;             // training only: [tiles][TrainLayout::a_slots][64][16] activations for the backward
     long M;
     int spr;                 // samples per ray
     MlpLayout lay;
 };
 
-template <int OT>
-__device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __restrict__ b, int h) {
-#pragma unroll
-    for (int t = 0; t < OT; ++t) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(b + (t * 2 + h) * 16);
-        const f32x4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-        acc[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
-                          v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
-    }
-}
-
-// One part of a layer: NQ quads of 4 k-steps. Quad q's A fragments (one 16-byte load per out-tile and
-// lane) are requested one quad AHEAD of the 4*OT MFMAs that consume them, so the ~2048 MFMA cycles of a
-// quad cover the L2 latency of the next one (one wave per SIMD: nothing else would hide it).
-// bsel(q, e) yields the B operand (a register of the previous layer / of the encoding) for k-step 4q+e;
-// q and e are compile-time constants after unrolling, so it is a plain register reference.
-template <int OT, int NQ, typename BSel>
-__device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __restrict__ w, int lane, BSel bsel) {
-    const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
-    f32x4 cur[OT], nxt[OT];
-#pragma unroll
-    for (int t = 0; t < OT; ++t) cur[t] = wp[t * 64];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (q + 1 < NQ) {
-#pragma unroll
-            for (int t = 0; t < OT; ++t) nxt[t] = wp[((q + 1) * OT + t) * 64];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < OT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][e], bsel(q, e), acc[t], 0, 0, 0);
-        if (q + 1 < NQ) {
-#pragma unroll
-            for (int t = 0; t < OT; ++t) cur[t] = nxt[t];
-        }
-    }
-}
-
-template <int OT, int NQ>
-__device__ __forceinline__ void mfma_scalars(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
-                                             const float (&bsrc)[4 * NQ]) {
-    mfma_part<OT, NQ>(acc, w, lane, [&](int q, int e) { return bsrc[4 * q + e]; });
-}
-
-// NT*4 quads whose B operands are the previous layer's accumulator registers
-template <int OT, int NT>
-__device__ __forceinline__ void mfma_acts(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
-                                          const f32x16 (&in)[NT]) {
-    mfma_part<OT, NT * 4>(acc, w, lane, [&](int q, int e) { return in[q >> 2][4 * (q & 3) + e]; });
-}
-
-template <int NT>
-__device__ __forceinline__ void relu_to(f32x16 (&dst)[NT], const f32x16 (&src)[NT], bool relu) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[t][r] = relu ? fmaxf(src[t][r], 0.f) : src[t][r];
-}
-
-template <int NT>
+template <int NT, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
     constexpr int OTV = NT / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -258,10 +149,20 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
         }
 
         f32x16 act[NT], acc[NT];
+        float* __restrict__ A = nullptr;     // this tile's activation slots (training)
+        if (TRAIN) {
+            A = a.acts + (size_t)tile * ((3 + (L.D + 1) * NT + NT / 2) * 1024);
+            f32x16 e0, e1, dv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { e0[r] = emb[r]; e1[r] = emb[16 + r]; dv[r] = demb[r]; }
+            f32x16 ev[3] = {e0, e1, dv};
+            store_tiles<3>(A, ev, lane);
+        }
         // ---- layer 0: 63 -> W
         load_bias<NT>(acc, P + L.b_off[0], h);
         mfma_scalars<NT, kEmbQuads>(acc, P + L.w_off[0], lane, emb);
         relu_to<NT>(act, acc, true);
+        if (TRAIN) store_tiles<NT>(A + 3 * 1024, act, lane);
 
         // ---- layers 1..D-1 (pts_linears, ReLU) and D (feature_linear, no activation)
         float alpha = 0.f;
@@ -291,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
             }
             mfma_acts<NT, NT>(acc, w, lane, act);
             relu_to<NT>(act, acc, l < L.D);
+            if (TRAIN) store_tiles<NT>(A + (3 + l * NT) * 1024, act, lane);   // H_{l+1} for l < D, F for l == D
         }
 
         // ---- views_linears[0]: cat([feature, embedded dirs]) -> W/2, ReLU (RH:112-116)
@@ -298,6 +200,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
         load_bias<OTV>(hv, P + L.b_off[L.D + 1], h);
         mfma_acts<OTV, NT>(hv, P + L.w_off[L.D + 1], lane, act);
         mfma_scalars<OTV, kDirQuads>(hv, P + L.w_off[L.D + 1] + NT * 4 * OTV * 256, lane, demb);
+        if (TRAIN) {
+            f32x16 hvr[OTV];
+            relu_to<OTV>(hvr, hv, true);
+            store_tiles<OTV>(A + (3 + (L.D + 1) * NT) * 1024, hvr, lane);
+        }
 
         // ---- rgb_linear: W/2 -> 3 (RH:118)
         const float* wr = P + L.rgb_off;
@@ -333,10 +240,11 @@ static int launch_mlp(const MlpArgs& a, int W, hipStream_t s) {
     long blocks = (ntiles + 3) / 4;
     if (blocks > cus) blocks = cus;      // persistent: one 4-wave workgroup per CU, one wave per SIMD
     const dim3 grid((unsigned)blocks), block(256);
+    const bool train = a.acts != nullptr;
     switch (W) {
-        case 256: nerf_mlp_fwd_kernel<8><<<grid, block, 0, s>>>(a); break;
-        case 128: nerf_mlp_fwd_kernel<4><<<grid, block, 0, s>>>(a); break;
-        case 64: nerf_mlp_fwd_kernel<2><<<grid, block, 0, s>>>(a); break;
+        case 256: if (train) nerf_mlp_fwd_kernel<8, true><<<grid, block, 0, s>>>(a); else nerf_mlp_fwd_kernel<8, false><<<grid, block, 0, s>>>(a); break;
+        case 128: if (train) nerf_mlp_fwd_kernel<4, true><<<grid, block, 0, s>>>(a); else nerf_mlp_fwd_kernel<4, false><<<grid, block, 0, s>>>(a); break;
+        case 64: if (train) nerf_mlp_fwd_kernel<2, true><<<grid, block, 0, s>>>(a); else nerf_mlp_fwd_kernel<2, false><<<grid, block, 0, s>>>(a); break;
         default: set_error("nerfail_mlp_fwd: unsupported W"); return NERFAIL_EINVAL;
     }
     NF_LAUNCHED("nerf_mlp_fwd_kernel");
@@ -397,7 +305,7 @@ extern "C" int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, cons
     NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
     if (M == 0) return NERFAIL_OK;
     NF_REQUIRE(packed != nullptr && pts != nullptr && viewdirs != nullptr && raw != nullptr, "NULL pointer");
-    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.raw = raw; a.M = M; a.spr = samples_per_ray;
+    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.raw = raw; a.acts = nullptr; a.M = M; a.spr = samples_per_ray;
     return launch_mlp(a, W, as_stream(stream));
 }
 
@@ -408,6 +316,24 @@ extern "C" int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int s
     NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
     if (M == 0) return NERFAIL_OK;
     NF_REQUIRE(packed != nullptr && x != nullptr && raw != nullptr, "NULL pointer");
-    a.packed = packed; a.pts = nullptr; a.viewdirs = nullptr; a.xemb = x; a.raw = raw; a.M = M; a.spr = 1;
+    a.packed = packed; a.pts = nullptr; a.viewdirs = nullptr; a.xemb = x; a.raw = raw; a.acts = nullptr; a.M = M; a.spr = 1;
+    return launch_mlp(a, W, as_stream(stream));
+}
+
+extern "C" size_t nerfail_mlp_train_acts_floats(int D, int W, int64_t M) {
+    MlpLayout L;
+    if (!make_layout(D, W, -1, L) || M < 0) return 0;
+    return (size_t)((M + 31) / 32) * make_train_layout(D, W).a_slots * 1024;
+}
+
+extern "C" int nerfail_mlp_fwd_train(const float* packed, int D, int W, int skip, const float* pts, const float* viewdirs,
+                                     int64_t M, int samples_per_ray, float* raw, float* acts, void* stream) {
+    NF_REQUIRE(M >= 0, "M is negative");
+    NF_REQUIRE(samples_per_ray >= 1, "samples_per_ray must be positive");
+    MlpArgs a;
+    NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(packed != nullptr && pts != nullptr && viewdirs != nullptr && raw != nullptr && acts != nullptr, "NULL pointer");
+    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.raw = raw; a.acts = acts; a.M = M; a.spr = samples_per_ray;
     return launch_mlp(a, W, as_stream(stream));
 }

@@ -1,0 +1,431 @@
+// K4b: backward of the fused NeRF MLP (autograd of run_nerf_helpers.py:100-123 inside loss.backward(), RN:791).
+//
+// Two kernels, both on v_mfma_f32_32x32x2_f32, both reading the activations that nerfail_mlp_fwd_train saved in
+// "fragment layout" (mlp_layout.h):
+//
+//  1. nerf_mlp_bwd_data_kernel: the backward-data chain dX = W^T dZ, register resident exactly like the
+//     forward: dZ of a layer sits in the accumulator layout (sample on the lane, channel on the register), which
+//     is the B operand of the next (earlier) layer's MFMA with A = a 32-row slab of W^T (packed once by
+//     nerfail_mlp_pack_T). ReLU masks come from the saved post-ReLU activations (h > 0 <=> pre-activation > 0).
+//     Every dZ is stored (fragment layout) for kernel 2. No gradient w.r.t. points/dirs is needed (RN:394 detaches
+//     z_samples; rays are data), so the chain stops at layer 1.
+//
+//  2. nerf_mlp_bwd_weights_kernel: dW[o][i] = sum_samples dZ[o][s] X[i][s], a contraction over SAMPLES, i.e. the
+//     MFMA k index is the sample. Both operands are needed as "channel on the lane, sample on k" - the transpose of
+//     how they were stored - but the fragment layout makes that transpose free: the element (channel c, sample j)
+//     of a slot lives at a closed-form address, and one wave-wide dword load (lane = channel, half = sample parity)
+//     touches just four 64-byte segments. So operands go global -> VGPR -> MFMA with no LDS and no shuffles.
+//     A wave owns a 128 x 128 block of one layer's dW (4x4 accumulator tiles, 256 registers) over a chunk of
+//     sample tiles and adds it to the gradient with float atomics shaped as two 128-byte runs per instruction;
+//     bias gradients fall out of the A operands (row sums) for free.
+#include "mlp_layout.h"
+
+namespace nerfail {
+
+// ------------------------------------------------------------------------------------- W^T packing
+// [quad][in-tile t][lane (i = l&31 -> input channel 32t+i, h = l>>5)][e]: W[o = out channel of k-step 4q+e in half h][col0 + 32t + i]
+__global__ void pack_layer_T_kernel(const float* __restrict__ w, int out_f, int in_f, int col0, int NT, int total,
+                                    float* __restrict__ wq) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int e = g & 3, lane = (g >> 2) & 63, rest = g >> 8;
+    const int t = rest % NT, q = rest / NT;
+    const int s = 4 * q + e, hh = lane >> 5;
+    const int o = 32 * (s / 16) + acc_channel(s % 16, hh);
+    const int i = 32 * t + (lane & 31);
+    wq[g] = (o < out_f) ? w[(long)o * in_f + col0 + i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------- backward data
+struct BwdArgs {
+    const float* packed;     // forward image (alpha / rgb head weights)
+    const float* packedT;    // transposed image
+    const float* d_raw;      // [M,4]
+    const float* acts;       // saved activations
+    float* dz;               // out: all dZ
+    long M;
+    MlpLayout lay;
+    MlpLayoutT layT;
+    TrainLayout tl;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_kernel(BwdArgs a) {
+    constexpr int OTV = NT / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const float* __restrict__ P = a.packed;
+    const float* __restrict__ PT = a.packedT;
+    const MlpLayout& L = a.lay;
+    const TrainLayout& TL = a.tl;
+    const long ntiles = (a.M + 31) / 32;
+    const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);
+
+    for (long rnd = 0; rnd < nrounds; ++rnd) {
+        const long tile = (rnd * gridDim.x + blockIdx.x) * 4 + wave;
+        if (tile >= ntiles) break;
+        const long sraw = tile * 32 + j;
+        const float* __restrict__ A = a.acts + (size_t)tile * TL.a_slots * 1024;
+        float* __restrict__ Z = a.dz + (size_t)tile * TL.z_slots * 1024;
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sraw < a.M) dr = reinterpret_cast<const float4*>(a.d_raw)[sraw];   // padded samples carry zero gradient
+
+        // ---- ZR: d_raw as a tile (channels 0..3 live in half 0, registers 0..3)
+        {
+            f32x16 zr[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zr[0][r] = 0.f;
+            if (h == 0) { zr[0][0] = dr.x; zr[0][1] = dr.y; zr[0][2] = dr.z; zr[0][3] = dr.w; }
+            store_tiles<1>(Z + TL.z_ZR * 1024, zr, lane);
+        }
+        // ---- rgb_linear backward: dZ_v = (W_rgb^T d_rgb) * [hv > 0]
+        f32x16 dzv[OTV];
+        {
+            const float* wr = P + L.rgb_off;
+#pragma unroll
+            for (int t = 0; t < OTV; ++t) {
+                const f32x16 hvt = load_tile(A + (TL.a_HV + t) * 1024, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = wr[((0 * OTV + t) * 2 + h) * 16 + r] * dr.x + wr[((1 * OTV + t) * 2 + h) * 16 + r] * dr.y +
+                                    wr[((2 * OTV + t) * 2 + h) * 16 + r] * dr.z;
+                    dzv[t][r] = hvt[r] > 0.f ? g : 0.f;
+                }
+            }
+            store_tiles<OTV>(Z + TL.z_ZV * 1024, dzv, lane);
+        }
+        // ---- views_linears[0] backward (feature columns): d_feature = Wv[:, :W]^T dZ_v
+        f32x16 cur[NT], nxt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cur[t][r] = 0.f;
+        mfma_part<NT, OTV * 4>(cur, PT + a.layT.w_off[L.D + 1], lane, [&](int q, int e) { return dzv[q >> 2][4 * (q & 3) + e]; });
+        store_tiles<NT>(Z + TL.z_ZF * 1024, cur, lane);         // feature_linear has no activation: dZ_F = d_feature
+        // ---- feature_linear + alpha_linear backward: d_h = Wf^T d_feature + w_alpha * d_sigma
+        {
+            const float* wa = P + L.alpha_off;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nxt[t][r] = wa[(t * 2 + h) * 16 + r] * dr.w;
+        }
+        mfma_acts<NT, NT>(nxt, PT + a.layT.w_off[L.D], lane, cur);
+        // ---- pts_linears[D-1 .. 0]
+#pragma unroll 1
+        for (int i = L.D - 1; i >= 0; --i) {
+            // dZ_i = d_h_{i+1} * [h_{i+1} > 0]
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x16 ht = load_tile(A + (TL.a_H1 + i * NT + t) * 1024, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cur[t][r] = ht[r] > 0.f ? nxt[t][r] : 0.f;
+            }
+            store_tiles<NT>(Z + (TL.z_Z0 + i * NT) * 1024, cur, lane);
+            if (i == 0) break;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nxt[t][r] = 0.f;
+            mfma_acts<NT, NT>(nxt, PT + a.layT.w_off[i], lane, cur);     // d_h_i = W_i[:, h-part]^T dZ_i
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- backward weights
+struct XPart {
+    int slot0, ntiles, kind;   // kind 0: accumulator-layout activation tiles, 1: pts encoding (10 bands), 2: dir encoding (4 bands)
+    int col0, ncols;           // destination columns [col0, col0 + ncols) of the weight gradient
+};
+struct LinDesc {
+    int dz_slot0, dz_tiles;    // dZ slots (out tiles)
+    int row0, row1;            // valid out rows (within the dZ tiles) -> gradient rows row - row0
+    int in_f;                  // row stride of the gradient
+    int nparts;
+    XPart parts[2];
+    float* gw;
+    float* gb;
+};
+constexpr int kMaxDesc = 14, kMaxTasks = 72;
+struct WTask { unsigned char desc, ob, part, ib; };
+struct WArgs {
+    const float* acts;
+    const float* dz;
+    long ntiles;               // 32-sample tiles
+    int tiles_per_chunk;
+    int a_slots, z_slots;
+    int ndesc, ntasks;
+    LinDesc desc[kMaxDesc];
+    WTask tasks[kMaxTasks];
+};
+
+// (slot offset, half, register) of channel `ch` (0..31 of a tile, or an encoding channel) in fragment layout
+__device__ __forceinline__ bool frag_coord(int kind, int tile, int ch, int& slot, int& hh, int& reg) {
+    if (kind == 0) { slot = tile; hh = (ch >> 2) & 1; reg = (ch & 3) + 4 * (ch >> 3); return true; }
+    const int bands = (kind == 1) ? 10 : 4;
+    const int c = 32 * tile + ch;
+    int s;
+    if (c < 2) { s = 3 * bands; hh = c; }
+    else if (c == 2) { s = 3 * bands + 1; hh = 0; }
+    else if (c < 3 + 6 * bands) { const int f = (c - 3) / 6, rem = (c - 3) % 6; hh = rem / 3; s = 3 * f + rem % 3; }
+    else { slot = 0; hh = 0; reg = 0; return false; }
+    slot = s >> 4; reg = s & 15;
+    return true;
+}
+
+__global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_kernel(WArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task_id = blockIdx.x * 4 + wave;
+    if (task_id >= a.ntasks) return;
+    const WTask tk = a.tasks[task_id];
+    const LinDesc& d = a.desc[tk.desc];
+    const XPart& xp = d.parts[tk.part];
+    const int c = lane & 31, kh = lane >> 5;
+
+    // per-lane operand offsets (floats) inside one sample tile, for k-step 0; step st adds 32*st (two samples on)
+    int offA[4], offB[4];
+    bool okA[4], okB[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int tt = 4 * tk.ob + m;
+        int slot, hh, reg;
+        frag_coord(0, tt, c, slot, hh, reg);
+        okA[m] = tt < d.dz_tiles;
+        offA[m] = ((d.dz_slot0 + (okA[m] ? slot : 0)) * 64 + hh * 32 + kh) * 16 + reg;
+        const int tb = 4 * tk.ib + m;
+        int slotb, hb, regb;
+        const bool valid = frag_coord(xp.kind, tb, c, slotb, hb, regb);
+        okB[m] = tb < xp.ntiles && valid;
+        offB[m] = ((xp.slot0 + (okB[m] ? slotb : 0)) * 64 + hb * 32 + kh) * 16 + regb;
+    }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = (d.gb != nullptr) && tk.part == 0 && tk.ib == 0;
+
+    const long t_begin = (long)blockIdx.y * a.tiles_per_chunk;
+    long t_end = t_begin + a.tiles_per_chunk;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    for (long ts = t_begin; ts < t_end; ++ts) {
+        const float* __restrict__ zb = a.dz + (size_t)ts * a.z_slots * 1024;
+        const float* __restrict__ xb = a.acts + (size_t)ts * a.a_slots * 1024;
+        float av[4], bv[4], an[4], bn[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { av[m] = okA[m] ? zb[offA[m]] : 0.f; bv[m] = okB[m] ? xb[offB[m]] : 0.f; }
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            if (st + 1 < 16) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    an[m] = okA[m] ? zb[offA[m] + 32 * (st + 1)] : 0.f;
+                    bn[m] = okB[m] ? xb[offB[m] + 32 * (st + 1)] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) rowsum[m] += av[m];
+            }
+            if (st + 1 < 16) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { av[m] = an[m]; bv[m] = bn[m]; }
+            }
+        }
+    }
+    // ---- add the block into the gradient: lane = column (input channel), registers = rows (output channels)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int tt = 4 * tk.ob + m;
+        if (tt >= d.dz_tiles) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int tb = 4 * tk.ib + n;
+            const int col = 32 * tb + c;
+            if (tb >= xp.ntiles || col >= xp.ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * tt + acc_channel(r, kh);
+                if (row >= d.row0 && row < d.row1)
+                    atomicAdd(d.gw + (long)(row - d.row0) * d.in_f + xp.col0 + col, acc[m][n][r]);
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float sres = rowsum[m] + __shfl_xor(rowsum[m], 32, 64);
+            const int row = 32 * (4 * tk.ob + m) + c;
+            if (kh == 0 && 4 * tk.ob + m < d.dz_tiles && row >= d.row0 && row < d.row1) atomicAdd(d.gb + (row - d.row0), sres);
+        }
+    }
+}
+
+static int cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace nerfail
+
+using namespace nerfail;
+
+extern "C" size_t nerfail_mlp_packed_T_floats(int D, int W, int skip) {
+    MlpLayout L;
+    if (!make_layout(D, W, skip, L)) return 0;
+    MlpLayoutT T;
+    make_layout_T(D, L.NT, T);
+    return (size_t)T.total;
+}
+
+extern "C" size_t nerfail_mlp_train_dz_floats(int D, int W, int64_t M) {
+    MlpLayout L;
+    if (!make_layout(D, W, -1, L) || M < 0) return 0;
+    return (size_t)((M + 31) / 32) * make_train_layout(D, W).z_slots * 1024;
+}
+
+extern "C" int nerfail_mlp_pack_T(const nerfail_mlp_params* p, float* packedT, void* stream) {
+    NF_REQUIRE(p != nullptr && packedT != nullptr, "NULL pointer");
+    MlpLayout L;
+    NF_REQUIRE(make_layout(p->D, p->W, p->skip, L), "unsupported (D, W)");
+    MlpLayoutT T;
+    make_layout_T(p->D, L.NT, T);
+    hipStream_t s = as_stream(stream);
+    const int W = p->W, NT = L.NT;
+    for (int l = 1; l <= p->D + 1; ++l) {
+        const float* w;
+        int out_f, in_f, col0 = 0;
+        if (l < p->D) {
+            NF_REQUIRE(p->pts_w[l] != nullptr, "pts_linears pointer is NULL");
+            const bool emb = layer_has_emb(l, L.skip);
+            w = p->pts_w[l]; out_f = W; in_f = emb ? W + kPtsCh : W; col0 = emb ? kPtsCh : 0;
+        } else if (l == p->D) {
+            NF_REQUIRE(p->feature_w != nullptr, "feature_linear pointer is NULL");
+            w = p->feature_w; out_f = W; in_f = W;
+        } else {
+            NF_REQUIRE(p->views_w != nullptr, "views_linears pointer is NULL");
+            w = p->views_w; out_f = W / 2; in_f = W + kDirCh;
+        }
+        const int total = (int)(((l == p->D + 1) ? (NT / 2) * 4 : NT * 4) * NT * 256);
+        pack_layer_T_kernel<<<dim3((total + 255) / 256), dim3(256), 0, s>>>(w, out_f, in_f, col0, NT, total, packedT + T.w_off[l]);
+        NF_LAUNCHED("pack_layer_T_kernel");
+    }
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_mlp_bwd_data(const float* packed, const float* packedT, int D, int W, int skip, const float* d_raw,
+                                    const float* acts, int64_t M, float* dz, void* stream) {
+    NF_REQUIRE(M >= 0, "M is negative");
+    BwdArgs a;
+    NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(packed && packedT && d_raw && acts && dz, "NULL pointer");
+    make_layout_T(D, a.lay.NT, a.layT);
+    a.tl = make_train_layout(D, W);
+    a.packed = packed; a.packedT = packedT; a.d_raw = d_raw; a.acts = acts; a.dz = dz; a.M = M;
+    const long ntiles = (M + 31) / 32;
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > cu_count()) blocks = cu_count();
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = as_stream(stream);
+    switch (W) {
+        case 256: nerf_mlp_bwd_data_kernel<8><<<grid, block, 0, s>>>(a); break;
+        case 128: nerf_mlp_bwd_data_kernel<4><<<grid, block, 0, s>>>(a); break;
+        case 64: nerf_mlp_bwd_data_kernel<2><<<grid, block, 0, s>>>(a); break;
+        default: set_error("nerfail_mlp_bwd_data: unsupported W"); return NERFAIL_EINVAL;
+    }
+    NF_LAUNCHED("nerf_mlp_bwd_data_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
+                                       const nerfail_mlp_params* grads_host, void* stream) {
+    NF_REQUIRE(M >= 0, "M is negative");
+    MlpLayout L;
+    NF_REQUIRE(make_layout(D, W, skip, L), "unsupported (D, W)");
+    NF_REQUIRE(grads_host != nullptr, "grads_host is NULL");
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(acts && dz, "NULL pointer");
+    const nerfail_mlp_params& g = *grads_host;
+    const TrainLayout TL = make_train_layout(D, W);
+    const int NT = L.NT, OTV = NT / 2;
+    WArgs a;
+    a.acts = acts; a.dz = dz; a.ntiles = (M + 31) / 32; a.a_slots = TL.a_slots; a.z_slots = TL.z_slots;
+    int nd = 0;
+    auto add = [&](int dz_slot0, int dz_tiles, int row0, int row1, int in_f, float* gw, float* gb) -> LinDesc& {
+        LinDesc& d = a.desc[nd++];
+        d.dz_slot0 = dz_slot0; d.dz_tiles = dz_tiles; d.row0 = row0; d.row1 = row1; d.in_f = in_f; d.gw = gw; d.gb = gb;
+        d.nparts = 0;
+        return d;
+    };
+    auto part = [&](LinDesc& d, int slot0, int ntiles, int kind, int col0, int ncols) {
+        XPart& p = d.parts[d.nparts++];
+        p.slot0 = slot0; p.ntiles = ntiles; p.kind = kind; p.col0 = col0; p.ncols = ncols;
+    };
+    NF_REQUIRE(D + 4 <= kMaxDesc, "network too deep for the weight-gradient descriptor table");
+    for (int i = 0; i < D; ++i) {
+        NF_REQUIRE(g.pts_w[i] != nullptr && g.pts_b[i] != nullptr, "pts_linears gradient pointer is NULL");
+        const bool emb = layer_has_emb(i, L.skip);
+        const int in_f = (i == 0) ? kPtsCh : (emb ? W + kPtsCh : W);
+        LinDesc& d = add(TL.z_Z0 + i * NT, NT, 0, W, in_f, (float*)g.pts_w[i], (float*)g.pts_b[i]);
+        if (emb) part(d, TL.a_E, 2, 1, 0, kPtsCh);
+        if (i > 0) part(d, TL.a_H1 + (i - 1) * NT, NT, 0, emb ? kPtsCh : 0, W);
+    }
+    NF_REQUIRE(g.feature_w && g.feature_b && g.views_w && g.views_b && g.alpha_w && g.alpha_b && g.rgb_w && g.rgb_b,
+               "head gradient pointer is NULL");
+    {
+        LinDesc& d = add(TL.z_ZF, NT, 0, W, W, (float*)g.feature_w, (float*)g.feature_b);
+        part(d, TL.a_H1 + (D - 1) * NT, NT, 0, 0, W);
+    }
+    {
+        LinDesc& d = add(TL.z_ZV, OTV, 0, W / 2, W + kDirCh, (float*)g.views_w, (float*)g.views_b);
+        part(d, TL.a_F, NT, 0, 0, W);
+        part(d, TL.a_V, 1, 2, W, kDirCh);
+    }
+    {   // rgb_linear: rows 0..2 of d_raw against hv
+        LinDesc& d = add(TL.z_ZR, 1, 0, 3, W / 2, (float*)g.rgb_w, (float*)g.rgb_b);
+        part(d, TL.a_HV, OTV, 0, 0, W / 2);
+    }
+    {   // alpha_linear: row 3 of d_raw against the last pts activation
+        LinDesc& d = add(TL.z_ZR, 1, 3, 4, W, (float*)g.alpha_w, (float*)g.alpha_b);
+        part(d, TL.a_H1 + (D - 1) * NT, NT, 0, 0, W);
+    }
+    a.ndesc = nd;
+    int nt = 0;
+    for (int di = 0; di < nd; ++di) {
+        const LinDesc& d = a.desc[di];
+        for (int ob = 0; ob < (d.dz_tiles + 3) / 4; ++ob)
+            for (int p = 0; p < d.nparts; ++p)
+                for (int ib = 0; ib < (d.parts[p].ntiles + 3) / 4; ++ib) {
+                    NF_REQUIRE(nt < kMaxTasks, "too many weight-gradient tasks");
+                    a.tasks[nt].desc = (unsigned char)di; a.tasks[nt].ob = (unsigned char)ob;
+                    a.tasks[nt].part = (unsigned char)p; a.tasks[nt].ib = (unsigned char)ib;
+                    ++nt;
+                }
+    }
+    a.ntasks = nt;
+    // enough (task, chunk) waves to fill the chip ~4x over; chunks of at least 16 tiles
+    const long want_chunks = (4L * cu_count() * 4 + nt - 1) / nt;
+    long tpc = (a.ntiles + want_chunks - 1) / want_chunks;
+    if (tpc < 16) tpc = 16;
+    a.tiles_per_chunk = (int)tpc;
+    const long nchunks = (a.ntiles + tpc - 1) / tpc;
+    const dim3 grid((unsigned)((nt + 3) / 4), (unsigned)nchunks), block(256);
+    nerf_mlp_bwd_weights_kernel<<<grid, block, 0, as_stream(stream)>>>(a);
+    NF_LAUNCHED("nerf_mlp_bwd_weights_kernel");
+    return NERFAIL_OK;
+}

@@ -1,0 +1,173 @@
+// Shared layout definitions of the fused NeRF MLP kernels (forward, backward-data, weight-gradient).
+#pragma once
+#include "common.h"
+
+namespace nerfail {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPtsCh = 63, kDirCh = 27;
+constexpr int kEmbQuads = 8;   // 32 k-steps: 30 sin/cos pairs + (x|y) + (z|pad)
+constexpr int kDirQuads = 4;   // 16 k-steps: 12 sin/cos pairs + (x|y) + (z|pad) + 2 zero steps
+
+// Input channel of a positional encoding (RH:47-50 order: x(3), then per band sin(3), cos(3))
+// consumed by k-step s in lane half h; -1 = zero padding. `bands` = 10 (pts) or 4 (dirs).
+__host__ __device__ inline int enc_channel(int s, int h, int bands) {
+    if (s < 3 * bands) return 3 + 6 * (s / 3) + 3 * h + (s % 3);
+    if (s == 3 * bands) return h;               // x | y
+    if (s == 3 * bands + 1) return h ? -1 : 2;  // z | pad
+    return -1;
+}
+// Channel of a 32-channel accumulator tile held in register r of lane half h (32x32 C/D layout).
+__host__ __device__ inline int acc_channel(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct MlpLayout {
+    int NT, D, skip;
+    unsigned w_off[NERFAIL_MAX_DEPTH + 2];   // [0..D-1] pts layers, [D] feature, [D+1] views
+    unsigned b_off[NERFAIL_MAX_DEPTH + 2];
+    unsigned alpha_off, rgb_off, total;
+};
+
+static inline bool layer_has_emb(int l, int skip) { return l == 0 || (skip >= 0 && l == skip + 1); }
+
+static bool make_layout(int D, int W, int skip, MlpLayout& L) {
+    if (!(W == 64 || W == 128 || W == 256)) return false;
+    if (D < 2 || D > NERFAIL_MAX_DEPTH) return false;
+    if (skip >= D - 1) skip = -1;    // `if i in skips` never fires for the last layer's successor (RH:106)
+    L.NT = W / 32; L.D = D; L.skip = skip;
+    const int NT = L.NT, OTV = NT / 2;
+    unsigned off = 0;
+    for (int l = 0; l <= D + 1; ++l) {
+        const int OT = (l == D + 1) ? OTV : NT;
+        int quads = 0;
+        if (l <= D - 1 && layer_has_emb(l, skip)) quads += kEmbQuads;
+        if (l > 0) quads += NT * 4;
+        if (l == D + 1) quads += kDirQuads;
+        L.w_off[l] = off; off += (unsigned)quads * OT * 256;
+        L.b_off[l] = off; off += (unsigned)OT * 32;
+    }
+    L.alpha_off = off; off += (unsigned)NT * 32 + 4;
+    L.rgb_off = off; off += 3u * OTV * 32 + 4;
+    L.total = off;
+    return true;
+}
+
+
+// ---- training buffers (fragment layout: [32-sample tile][slot][lane 0..63][16 registers]) ----------------
+// A "slot" is one 32-channel x 32-sample accumulator tile exactly as a wave holds it: lane l = (half h = l>>5,
+// sample j = l&31) stores its 16 registers (channels 32*tile + acc_channel(r, h)) as 64 contiguous bytes, so a
+// wave writes / reads 4 KB contiguous per slot.
+//   acts slots: E0 E1 (32 encoding k-steps of pts), V (16 encoding k-steps of dirs), H_1..H_D (NT each, post-ReLU
+//               outputs of pts_linears), F (NT, feature_linear output), HV (NT/2, post-ReLU views output)
+//   dz   slots: Z_0..Z_{D-1} (NT each, gradient w.r.t. the pre-activation of pts_linears[i]), ZF (NT), ZV (NT/2),
+//               ZR (1: d_raw, channels 0..3 = rgb, sigma)
+struct TrainLayout {
+    int NT, D, OTV;
+    int a_slots, a_E, a_V, a_H1, a_F, a_HV;
+    int z_slots, z_Z0, z_ZF, z_ZV, z_ZR;
+};
+static inline TrainLayout make_train_layout(int D, int W) {
+    TrainLayout t;
+    t.NT = W / 32; t.D = D; t.OTV = t.NT / 2;
+    t.a_E = 0; t.a_V = 2; t.a_H1 = 3; t.a_F = 3 + D * t.NT; t.a_HV = t.a_F + t.NT; t.a_slots = t.a_HV + t.OTV;
+    t.z_Z0 = 0; t.z_ZF = D * t.NT; t.z_ZV = t.z_ZF + t.NT; t.z_ZR = t.z_ZV + t.OTV; t.z_slots = t.z_ZR + 1;
+    return t;
+}
+
+// transposed-weight image for the backward-data pass: [layer 1..D-1, feature, views][quad][in-tile][lane][4]
+struct MlpLayoutT {
+    unsigned w_off[NERFAIL_MAX_DEPTH + 2];   // index l = 1..D-1 pts layers, D feature, D+1 views
+    unsigned total;
+};
+static inline void make_layout_T(int D, int NT, MlpLayoutT& L) {
+    unsigned off = 0;
+    for (int l = 0; l <= D + 1; ++l) {
+        L.w_off[l] = off;
+        if (l == 0) continue;
+        const int quads = (l == D + 1) ? (NT / 2) * 4 : NT * 4;
+        off += (unsigned)quads * NT * 256;
+    }
+    L.total = off;
+}
+
+// ---- device helpers shared by the forward and backward kernels -------------------------------------------
+template <int OT>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __restrict__ b, int h) {
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(b + (t * 2 + h) * 16);
+        const f32x4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        acc[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
+                          v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+    }
+}
+
+// One part of a layer: NQ quads of 4 k-steps. Quad q's A fragments (one 16-byte load per out-tile and
+// lane) are requested one quad AHEAD of the 4*OT MFMAs that consume them, so the ~2048 MFMA cycles of a
+// quad cover the L2 latency of the next one (one wave per SIMD: nothing else would hide it).
+// bsel(q, e) yields the B operand (a register of the previous layer / of the encoding) for k-step 4q+e;
+// q and e are compile-time constants after unrolling, so it is a plain register reference.
+template <int OT, int NQ, typename BSel>
+__device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __restrict__ w, int lane, BSel bsel) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
+    f32x4 cur[OT], nxt[OT];
+#pragma unroll
+    for (int t = 0; t < OT; ++t) cur[t] = wp[t * 64];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) nxt[t] = wp[((q + 1) * OT + t) * 64];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][e], bsel(q, e), acc[t], 0, 0, 0);
+        if (q + 1 < NQ) {
+#pragma unroll
+            for (int t = 0; t < OT; ++t) cur[t] = nxt[t];
+        }
+    }
+}
+
+template <int OT, int NQ>
+__device__ __forceinline__ void mfma_scalars(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
+                                             const float (&bsrc)[4 * NQ]) {
+    mfma_part<OT, NQ>(acc, w, lane, [&](int q, int e) { return bsrc[4 * q + e]; });
+}
+
+// NT*4 quads whose B operands are the previous layer's accumulator registers
+template <int OT, int NT>
+__device__ __forceinline__ void mfma_acts(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
+                                          const f32x16 (&in)[NT]) {
+    mfma_part<OT, NT * 4>(acc, w, lane, [&](int q, int e) { return in[q >> 2][4 * (q & 3) + e]; });
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_to(f32x16 (&dst)[NT], const f32x16 (&src)[NT], bool relu) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[t][r] = relu ? fmaxf(src[t][r], 0.f) : src[t][r];
+}
+
+// store / load NTILES accumulator tiles in fragment layout (64 B contiguous per lane and tile)
+template <int NTILES>
+__device__ __forceinline__ void store_tiles(float* __restrict__ base, const f32x16 (&a)[NTILES], int lane) {
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) {
+        f32x4* p = reinterpret_cast<f32x4*>(base + (t * 64 + lane) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[q] = (f32x4){a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]};
+    }
+}
+__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(base + lane * 16);
+    const f32x4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+    return (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
+                    v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+}
+
+}  // namespace nerfail

@@ -252,13 +252,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
     noise / noise_fine [R,N] (already scaled) supply the random draws explicitly.
     """
     dev = _cuda()
-    lib = _lib.load()
     rays = _lib.f32c(ray_batch, dev)
     if rays.shape[-1] != _lib.RAY_FLOATS:
         raise NotImplementedError('ray_batch must be [R, 11] (use_viewdirs=True packing, RN:116-123)')
     R = rays.shape[0]
-    viewdirs = rays[:, 8:11].contiguous()
-    st = _lib.stream()
+    q = network_query_fn
+    fused = q is None or (isinstance(q, FusedNetworkQuery) and _is_fused(q.embed_fn, q.embeddirs_fn, network_fn))
 
     if perturb > 0. and t_rand is None:
         if pytest:                                     # RN:374-377
@@ -266,39 +265,82 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
             t_rand = torch.Tensor(np.random.rand(R, N_samples))
         else:
             t_rand = torch.rand((R, N_samples), device=dev)
-    if perturb > 0.:
-        t_rand = _lib.f32c(t_rand, dev)
+    t_rand = _lib.f32c(t_rand, dev) if perturb > 0. else None
+    if N_importance > 0 and u is None:
+        det = (perturb == 0.)
+        if pytest:                                     # RH:215-223
+            np.random.seed(0)
+            u = torch.Tensor(np.linspace(0., 1., N_importance)) if det else torch.Tensor(np.random.rand(R, N_importance))
+        else:
+            u = linspace01(N_importance, dev) if det else torch.rand((R, N_importance), device=dev)
+    if u is not None:
+        u = _lib.f32c(u, dev)
+    nz = _noise((R, N_samples), raw_noise_std, pytest, noise, dev)
+    nzf = _noise((R, N_samples + N_importance), raw_noise_std, pytest, noise_fine, dev) if N_importance > 0 else None
+
+    def pipeline(rays, train=False):
+        return _render_rays_pipeline(rays, network_fn, network_fine, q if not fused else None, N_samples, N_importance,
+                                     lindisp, white_bkgd, t_rand, u, nz, nzf, want_pts_max, train)
+
+    needs_grad = fused and torch.is_grad_enabled() and any(
+        p.requires_grad for n in (network_fn, network_fine) if n is not None for p in n.parameters())
+    if needs_grad:
+        from . import _train
+        nets = [network_fn] + ([network_fine] if network_fine is not None else [])
+        params = [p for n in nets for p in _train.ordered_params(n)]
+        cfg = dict(pipeline=pipeline, network_fn=network_fn, network_fine=network_fine, white_bkgd=white_bkgd,
+                   retraw=retraw)
+        o = _train.RenderRaysTrain.apply(rays, cfg, *params)
+        out = dict(zip(('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'pts_max', 'raw'), o))
     else:
-        t_rand = None
+        out = pipeline(rays, False)
+
+    ret = {'rgb_map': out['rgb_map'], 'disp_map': out['disp_map'], 'acc_map': out['acc_map']}
+    if want_pts_max:
+        ret['pts_max'] = out['pts_max']
+    if retraw:
+        ret['raw'] = out['raw']
+    if N_importance > 0:
+        ret.update(rgb0=out['rgb0'], disp0=out['disp0'], acc0=out['acc0'], z_std=out['z_std'])
+    if DEBUG:
+        for k in ret:
+            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
+                print(f"! [Numerical Error] {k} contains nan or inf.")
+    return ret
+
+
+def _render_rays_pipeline(rays, network_fn, network_fine, user_query, N_samples, N_importance, lindisp, white_bkgd,
+                          t_rand, u, nz, nzf, want_pts_max, train):
+    """The kernel sequence of one chunk. `train` saves what the backward needs (activations, raw, z)."""
+    dev = rays.device
+    lib = _lib.load()
+    R = rays.shape[0]
+    st = _lib.stream()
+    viewdirs = rays[:, 8:11].contiguous()
+
+    def empty():
+        return torch.empty((0,), dtype=torch.float32, device=dev)
+
+    def query(p, fn):
+        if user_query is not None:
+            return _lib.f32c(user_query(p, viewdirs, fn), dev), None   # user-supplied query function (reference contract)
+        if train:
+            from . import _train
+            return _train.mlp_fwd_train(fn, p, viewdirs)
+        return _mlp_points(fn, p, viewdirs), None                      # fused encode + MLP, nothing materialised
 
     z_vals = torch.empty((R, N_samples), dtype=torch.float32, device=dev)
     pts = torch.empty((R, N_samples, 3), dtype=torch.float32, device=dev)
     _lib.check(lib.nerfail_sample_coarse(_lib.dev(rays), R, _lib.dev(linspace01(N_samples, dev)), int(N_samples),
                                          _lib.dev(t_rand, 't_rand'), int(bool(lindisp)), _lib.dev(z_vals), _lib.dev(pts), st))
-
-    def query(p, fn):
-        q = network_query_fn
-        if q is None or (isinstance(q, FusedNetworkQuery) and _is_fused(q.embed_fn, q.embeddirs_fn, fn)):
-            return _mlp_points(fn, p, viewdirs)          # fused encode + MLP, nothing materialised
-        return _lib.f32c(q(p, viewdirs, fn), dev)        # user-supplied query function (reference contract)
-
-    raw = query(pts, network_fn)
-    nz = _noise((R, N_samples), raw_noise_std, pytest, noise, dev)
+    raw, acts = query(pts, network_fn)
     last_pass = not (N_importance > 0)
     rgb_map, disp_map, acc_map, weights, depth_map, pts_max = _composite(
         raw, z_vals, rays, nz, white_bkgd, pts if (want_pts_max and last_pass) else None)
-
-    ret = {}
+    out = {'rgb0': empty(), 'disp0': empty(), 'acc0': empty(), 'z_std': empty()}
+    saved = {'rays': rays, 'coarse': dict(raw=raw, z=z_vals, acts=acts, noise=nz), 'fine': None}
     if N_importance > 0:
-        rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
-        det = (perturb == 0.)
-        if u is None:
-            if pytest:                                 # RH:215-223
-                np.random.seed(0)
-                u = torch.Tensor(np.linspace(0., 1., N_importance)) if det else torch.Tensor(np.random.rand(R, N_importance))
-            else:
-                u = linspace01(N_importance, dev) if det else torch.rand((R, N_importance), device=dev)
-        u = _lib.f32c(u, dev)
+        out.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
         Nt = N_samples + N_importance
         z_samples = torch.empty((R, N_importance), dtype=torch.float32, device=dev)
         z_fine = torch.empty((R, Nt), dtype=torch.float32, device=dev)
@@ -309,19 +351,13 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                                            _lib.dev(z_fine), _lib.dev(pts), _lib.dev(z_std), st))
         z_vals = z_fine
         run_fn = network_fn if network_fine is None else network_fine
-        raw = query(pts, run_fn)
-        nzf = _noise((R, Nt), raw_noise_std, pytest, noise_fine, dev)
+        raw, acts = query(pts, run_fn)
         rgb_map, disp_map, acc_map, weights, depth_map, pts_max = _composite(
             raw, z_vals, rays, nzf, white_bkgd, pts if want_pts_max else None)
-        ret.update(rgb0=rgb_map_0, disp0=disp_map_0, acc0=acc_map_0, z_std=z_std)
-
-    ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)
-    if want_pts_max:
-        ret['pts_max'] = pts_max
-    if retraw:
-        ret['raw'] = raw
-    if DEBUG:
-        for k in ret:
-            if torch.isnan(ret[k]).any() or torch.isinf(ret[k]).any():
-                print(f"! [Numerical Error] {k} contains nan or inf.")
-    return ret
+        out['z_std'] = z_std
+        saved['fine'] = dict(raw=raw, z=z_vals, acts=acts, noise=nzf)
+    out.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map, raw=raw,
+               pts_max=pts_max if pts_max is not None else empty())
+    if train:
+        out['_saved'] = saved
+    return out

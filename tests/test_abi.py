@@ -12,7 +12,7 @@ from conftest import ROOT
 def _declared():
     text = open(os.path.join(ROOT, 'include', 'nerfail_hip.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(nerfail_[a-z0-9_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(nerfail_[A-Za-z0-9_]+)\s*\(', text)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,119 @@
+"""-m gpu: the training step (row a12, run_nerf.py:776-791): loss.backward() through the HIP render path vs the
+reference's autograd (fixture g7) and the float64-accumulating oracle."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_err, l2_err
+from hiputil import T, N, hip_nerf, dev
+from oracle import nerf as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_raw2outputs(raw, z, rd, white):
+    """float64 torch restatement of RN:262-305 used only to differentiate every output w.r.t. raw."""
+    dists = torch.cat([z[..., 1:] - z[..., :-1], torch.full_like(z[..., :1], 1e10)], -1) * rd.norm(dim=-1, keepdim=True)
+    rgb = torch.sigmoid(raw[..., :3])
+    alpha = 1. - torch.exp(-torch.relu(raw[..., 3]) * dists)
+    T_ = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+    w = alpha * T_
+    rgb_map = (w[..., None] * rgb).sum(-2)
+    depth = (w * z).sum(-1)
+    acc = w.sum(-1)
+    disp = 1. / torch.max(1e-10 * torch.ones_like(depth), depth / acc)
+    if white:
+        rgb_map = rgb_map + (1. - acc[..., None])
+    return rgb_map, disp, acc, w, depth
+
+
+@pytest.mark.parametrize('Ns', [64, 192])
+@pytest.mark.parametrize('white', [False, True])
+def test_composite_backward_all_outputs(Ns, white):
+    from nerfail_amd._train import composite_backward
+    rs = np.random.RandomState(Ns)
+    R = 37
+    z = np.sort(rs.uniform(2, 6, (R, Ns)).astype(np.float32), -1)
+    raw = rs.normal(size=(R, Ns, 4)).astype(np.float32)
+    raw[..., 3] = raw[..., 3] * 2 + 0.5
+    rd = rs.normal(size=(R, 3)).astype(np.float32)
+    g = [rs.normal(size=s).astype(np.float32) for s in ((R, 3), (R,), (R,), (R, Ns), (R,))]
+    rt = torch.from_numpy(raw).double().requires_grad_(True)
+    outs = _torch_raw2outputs(rt, torch.from_numpy(z).double(), torch.from_numpy(rd).double(), white)
+    sum((o * torch.from_numpy(gi).double()).sum() for o, gi in zip(outs, g)).backward()
+    rays = np.zeros((R, 11), np.float32)
+    rays[:, 3:6] = rd
+    d_raw = composite_backward(T(raw), T(z), T(rays), None, white, T(g[0]), T(g[1]), T(g[2]), T(g[4]), T(g[3]))
+    assert l2_err(N(d_raw), rt.grad.numpy()) < 2e-4
+    # the loss of the training step touches rgb_map only: same thing against the oracle's closed form
+    d2 = composite_backward(T(raw), T(z), T(rays), None, white, T(g[0]), None, None)
+    assert l2_err(N(d2), O.raw2outputs_backward(raw, z, rd, g[0], white)) < 2e-4
+
+
+@pytest.mark.parametrize('tag,D,W', [('small', 4, 64), ('full', 8, 256)])
+def test_training_step_gradients(golden, tag, D, W):
+    from nerfail_amd import run_nerf as RN
+    g = golden('g7_train_grads')
+    sc, coarse = hip_nerf(D, W, 31, requires_grad=True)
+    sf, fine = hip_nerf(D, W, 32, requires_grad=True)
+    rays, target = g[tag + '_rays'], g[tag + '_target']
+    r = RN.render_rays(T(rays), coarse, None, 64, retraw=True, N_importance=128, network_fine=fine, white_bkgd=True,
+                       perturb=1., t_rand=T(g[tag + '_t_rand']), u=T(g[tag + '_u']))
+    loss = RN.img2mse(r['rgb_map'], T(target)) + RN.img2mse(r['rgb0'], T(target))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[tag + '_loss'])) < 1e-5 * abs(float(g[tag + '_loss']))
+    assert rel_err(N(r['rgb_map']), g[tag + '_rgb_map']) < 1e-4
+    ref = O.train_step_grads(rays, sc, sf, target, t_rand=g[tag + '_t_rand'], u=g[tag + '_u'], D=D, W=W)
+    for nm, net in (('coarse', coarse), ('fine', fine)):
+        for k, p in net.named_parameters():
+            got = N(p.grad)
+            assert l2_err(got, ref['grads_' + nm][k]) < 5e-3, (nm, k)              # vs the float64 oracle
+            if tag == 'small':                                                       # vs the reference's autograd
+                assert l2_err(got, g['small_%s_grad_%s' % (nm, k)]) < 5e-3, (nm, k)
+            else:
+                refn = float(g['full_%s_gradnorm_%s' % (nm, k)])
+                assert abs(np.linalg.norm(got.astype(np.float64)) - refn) < 5e-3 * refn, (nm, k)
+                assert l2_err(got.reshape(-1)[:256], g['full_%s_gradhead_%s' % (nm, k)]) < 5e-3, (nm, k)
+
+
+def test_training_loop_adam_reduces_loss():
+    """RN:776-801 shape of the loop: render -> mse -> backward -> Adam.step; weights change in place, so the packed
+    images must be rebuilt every step (cache keyed on parameter versions)."""
+    from nerfail_amd import run_nerf as RN
+    _, coarse = hip_nerf(4, 64, 41, requires_grad=True)
+    _, fine = hip_nerf(4, 64, 42, requires_grad=True)
+    opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    rays = T(synth.ray_batch(256, seed=7))
+    target = T(np.random.RandomState(0).uniform(size=(256, 3)).astype(np.float32))
+    gen = torch.Generator(device=dev()).manual_seed(0)
+    losses = []
+    for it in range(12):
+        t_rand = torch.rand((256, 64), device=dev(), generator=gen)
+        u = torch.rand((256, 128), device=dev(), generator=gen)
+        r = RN.render_rays(rays, coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.,
+                           t_rand=t_rand, u=u)
+        loss = RN.img2mse(r['rgb_map'], target) + RN.img2mse(r['rgb0'], target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] and np.isfinite(losses).all()
+
+
+def test_single_pass_and_shared_network_gradients():
+    """N_importance = 0 (cfg1) and network_fine=None (fine pass reuses network_fn, RN:399): grads still match the oracle."""
+    from nerfail_amd import run_nerf as RN
+    sd, net = hip_nerf(4, 64, 51, requires_grad=True)
+    rays = synth.ray_batch(40, seed=3)
+    target = np.random.RandomState(1).uniform(size=(40, 3)).astype(np.float32)
+    r = RN.render_rays(T(rays), net, None, 64, white_bkgd=True)
+    RN.img2mse(r['rgb_map'], T(target)).backward()
+    z0 = O.coarse_z_vals(rays[:, 6:7], rays[:, 7:8], 64)
+    pts0 = rays[:, None, 0:3] + rays[:, None, 3:6] * z0[:, :, None]
+    raw0, cache0 = O._mlp_forward_cached(sd, pts0.astype(np.float32), rays[:, -3:], 4, 64)
+    rgb0 = O.raw2outputs(raw0, z0, rays[:, 3:6], None, True)[0]
+    d0 = O.raw2outputs_backward(raw0, z0, rays[:, 3:6], 2.0 * (rgb0 - target) / rgb0.size, True)
+    ref = O.mlp_backward(sd, cache0, d0, 4, 64)
+    for k, p in net.named_parameters():
+        assert l2_err(N(p.grad), ref[k]) < 5e-3, k
