@@ -193,7 +193,9 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-attack', action='store_true')
+    ap.add_argument('--no-attack', action='store_true', help='skip the extra train / attack sections')
+    ap.add_argument('--sections', default='render,train,attack',
+                    help='comma list of render,train,attack (profiling aid; the JSON line needs render)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -209,6 +211,15 @@ def main():
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
 
     from nerfail_amd import nerf_to_coord as NC, run_nerf as RN
+    sections = set(args.sections.split(','))
+    if 'render' not in sections:                  # profiling aid: run only the requested extra sections
+        out = {}
+        if 'train' in sections:
+            out['train'] = train_bench(dev)
+        if 'attack' in sections:
+            out['attack'] = attack_bench(dev)
+        print(json.dumps(out), flush=True)
+        return
 
     _, coarse = make_net(21, dev)
     _, fine = make_net(22, dev)
@@ -256,6 +267,15 @@ def main():
         elapsed = float(t[0])
     assert torch.isfinite(out[0]).all()
 
+    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes of this same command (corrected as
+    # MI355X_MICROARCH.md prescribes); profiles/ travels with the repo, the counters cannot be read from inside bench.py
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))['kernels']
+        k = [v for n, v in pmc.items() if 'nerf_mlp_fwd_kernel' in n][0]
+        traffic = k['fetch_bytes_per_launch_corrected'] + k['write_bytes_per_launch']
+    except Exception:
+        pass
     mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in mlp_events)
     mlp_samples = sum(n for _, _, n in mlp_events)
     achieved = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
@@ -273,7 +293,8 @@ def main():
                        'parallelism': 'view-per-rank, no collective'},
             'roofline': {'bound': 'mfma', 'kernel': 'nerf_mlp_fwd_kernel<8>', 'achieved': achieved,
                          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                         'traffic': None, 'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
+                         'traffic': traffic, 'traffic_unit': 'HBM+IC bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
+                         'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
                          'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
         }
         if not args.no_cpu_baseline and world == 1:
@@ -281,8 +302,10 @@ def main():
         else:
             line['cpu_baseline'] = None
         if not args.no_attack and world == 1:
-            line['train'] = train_bench(dev)
-            line['attack'] = attack_bench(dev)
+            if 'train' in sections:
+                line['train'] = train_bench(dev)
+            if 'attack' in sections:
+                line['attack'] = attack_bench(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

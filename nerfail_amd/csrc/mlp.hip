@@ -94,7 +94,10 @@ struct MlpArgs {
 template <int NT, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
     constexpr int OTV = NT / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave id made PROVABLY wave-uniform: tile bases then live in SGPRs and every access is scalar-base + 32-bit
+    // lane offset instead of a 64-bit VGPR pair per address (which spilled hundreds of registers)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     const float* __restrict__ P = a.packed;
     const MlpLayout& L = a.lay;
@@ -152,11 +155,8 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
         float* __restrict__ A = nullptr;     // this tile's activation slots (training)
         if (TRAIN) {
             A = a.acts + (size_t)tile * ((3 + (L.D + 1) * NT + NT / 2) * 1024);
-            f32x16 e0, e1, dv;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { e0[r] = emb[r]; e1[r] = emb[16 + r]; dv[r] = demb[r]; }
-            f32x16 ev[3] = {e0, e1, dv};
-            store_tiles<3>(A, ev, lane);
+            store_enc<10, 4 * kEmbQuads>(A, emb, lane);              // E0 E1: 63 channels
+            store_enc<4, 4 * kDirQuads>(A + 2 * 1024, demb, lane);   // V: 27 channels
         }
         // ---- layer 0: 63 -> W
         load_bias<NT>(acc, P + L.b_off[0], h);
@@ -187,7 +187,15 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
             load_bias<NT>(acc, P + L.b_off[l], h);
             const float* w = P + L.w_off[l];
             if (l == L.skip + 1 && L.skip >= 0) {   // h = cat([input_pts, h]) (RH:106-107)
-                mfma_scalars<NT, kEmbQuads>(acc, w, lane, emb);
+                if (TRAIN) {
+                    // training: the encoding was saved to `acts`; reloading it here (instead of keeping 32 registers
+                    // live across the layer loop) leaves room for the double-buffered weight stream
+                    float e2[4 * kEmbQuads];
+                    load_enc<10, 4 * kEmbQuads>(A, e2, lane);
+                    mfma_scalars<NT, kEmbQuads>(acc, w, lane, e2);
+                } else {
+                    mfma_scalars<NT, kEmbQuads>(acc, w, lane, emb);
+                }
                 w += kEmbQuads * NT * 256;
             }
             mfma_acts<NT, NT>(acc, w, lane, act);
@@ -199,7 +207,13 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
         f32x16 hv[OTV];
         load_bias<OTV>(hv, P + L.b_off[L.D + 1], h);
         mfma_acts<OTV, NT>(hv, P + L.w_off[L.D + 1], lane, act);
-        mfma_scalars<OTV, kDirQuads>(hv, P + L.w_off[L.D + 1] + NT * 4 * OTV * 256, lane, demb);
+        if (TRAIN) {
+            float d2[4 * kDirQuads];
+            load_enc<4, 4 * kDirQuads>(A + 2 * 1024, d2, lane);
+            mfma_scalars<OTV, kDirQuads>(hv, P + L.w_off[L.D + 1] + NT * 4 * OTV * 256, lane, d2);
+        } else {
+            mfma_scalars<OTV, kDirQuads>(hv, P + L.w_off[L.D + 1] + NT * 4 * OTV * 256, lane, demb);
+        }
         if (TRAIN) {
             f32x16 hvr[OTV];
             relu_to<OTV>(hvr, hv, true);

@@ -1,7 +1,7 @@
 // K4b: backward of the fused NeRF MLP (autograd of run_nerf_helpers.py:100-123 inside loss.backward(), RN:791).
 //
-// Two kernels, both on v_mfma_f32_32x32x2_f32, both reading the activations that nerfail_mlp_fwd_train saved in
-// "fragment layout" (mlp_layout.h):
+// Two kernels, both on v_mfma_f32_32x32x2_f32, both reading the activations that nerfail_mlp_fwd_train saved as
+// channel-major tiles (mlp_layout.h):
 //
 //  1. nerf_mlp_bwd_data_kernel: the backward-data chain dX = W^T dZ, register resident exactly like the
 //     forward: dZ of a layer sits in the accumulator layout (sample on the lane, channel on the register), which
@@ -12,9 +12,9 @@
 //
 //  2. nerf_mlp_bwd_weights_kernel: dW[o][i] = sum_samples dZ[o][s] X[i][s], a contraction over SAMPLES, i.e. the
 //     MFMA k index is the sample. Both operands are needed as "channel on the lane, sample on k" - the transpose of
-//     how they were stored - but the fragment layout makes that transpose free: the element (channel c, sample j)
-//     of a slot lives at a closed-form address, and one wave-wide dword load (lane = channel, half = sample parity)
-//     touches just four 64-byte segments. So operands go global -> VGPR -> MFMA with no LDS and no shuffles.
+//     how the producers hold them - but the channel-major tile layout (mlp_layout.h) makes that transpose free: with
+//     the k-step mapping (step st, half kh) <-> sample 16*kh + st, lane (channel c, kh) reads 16 contiguous floats,
+//     four 16-byte loads for all 16 k-steps of a tile. Operands go global -> VGPR -> MFMA, no LDS, no shuffles.
 //     A wave owns a 128 x 128 block of one layer's dW (4x4 accumulator tiles, 256 registers) over a chunk of
 //     sample tiles and adds it to the gradient with float atomics shaped as two 128-byte runs per instruction;
 //     bias gradients fall out of the A operands (row sums) for free.
@@ -52,7 +52,10 @@ struct BwdArgs {
 template <int NT>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_kernel(BwdArgs a) {
     constexpr int OTV = NT / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave id made PROVABLY wave-uniform: tile bases then live in SGPRs and every access is scalar-base + 32-bit
+    // lane offset instead of a 64-bit VGPR pair per address (which spilled hundreds of registers)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
     const float* __restrict__ P = a.packed;
     const float* __restrict__ PT = a.packedT;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_kernel(BwdArgs a) {
 
 // ------------------------------------------------------------------------------------- backward weights
 struct XPart {
-    int slot0, ntiles, kind;   // kind 0: accumulator-layout activation tiles, 1: pts encoding (10 bands), 2: dir encoding (4 bands)
+    int slot0, ntiles, kind;   // kind is informational (0 activations, 1 pts encoding, 2 dir encoding): all slots are channel-major
     int col0, ncols;           // destination columns [col0, col0 + ncols) of the weight gradient
 };
 struct LinDesc {
@@ -152,105 +155,97 @@ struct WArgs {
     const float* acts;
     const float* dz;
     long ntiles;               // 32-sample tiles
-    int tiles_per_chunk;
     int a_slots, z_slots;
-    int ndesc, ntasks;
+    int ndesc, ntasks, ngroups;            // a group = 4 consecutive tasks = the 4 waves of a workgroup
+    int group_cost[kMaxTasks / 4 + 1];     // MFMAs per k-step of the group's heaviest task
+    long cum[kMaxTasks / 4 + 2];           // prefix sums of group_cost * ntiles (work units)
     LinDesc desc[kMaxDesc];
     WTask tasks[kMaxTasks];
 };
 
-// (slot offset, half, register) of channel `ch` (0..31 of a tile, or an encoding channel) in fragment layout
-__device__ __forceinline__ bool frag_coord(int kind, int tile, int ch, int& slot, int& hh, int& reg) {
-    if (kind == 0) { slot = tile; hh = (ch >> 2) & 1; reg = (ch & 3) + 4 * (ch >> 3); return true; }
-    const int bands = (kind == 1) ? 10 : 4;
-    const int c = 32 * tile + ch;
-    int s;
-    if (c < 2) { s = 3 * bands; hh = c; }
-    else if (c == 2) { s = 3 * bands + 1; hh = 0; }
-    else if (c < 3 + 6 * bands) { const int f = (c - 3) / 6, rem = (c - 3) % 6; hh = rem / 3; s = 3 * f + rem % 3; }
-    else { slot = 0; hh = 0; reg = 0; return false; }
-    slot = s >> 4; reg = s & 15;
-    return true;
-}
-
-__global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_kernel(WArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int task_id = blockIdx.x * 4 + wave;
-    if (task_id >= a.ntasks) return;
-    const WTask tk = a.tasks[task_id];
+// One task: an (MA x NB)-tile block of one layer's dW over one chunk of sample tiles. MA / NB are the numbers of
+// VALID out / in tiles of the block (4x4 for the 256-wide layers, 4x2 for the encoding columns, 4x1 for the view
+// encoding, 1x4 for the rgb / alpha heads), so no MFMA is spent on padding tiles.
+template <int MA, int NB>
+__device__ __forceinline__ void dw_task(const WArgs& a, const WTask tk, int lane, long t_begin, long t_end) {
     const LinDesc& d = a.desc[tk.desc];
     const XPart& xp = d.parts[tk.part];
     const int c = lane & 31, kh = lane >> 5;
-
-    // per-lane operand offsets (floats) inside one sample tile, for k-step 0; step st adds 32*st (two samples on)
-    int offA[4], offB[4];
-    bool okA[4], okB[4];
+    // per-lane operand offsets (floats) inside one sample tile: lane (c, kh) owns 16 contiguous floats (k-steps 0..15).
+    // Loads are UNCONDITIONAL (a padding channel reads its zero-filled row; a column beyond ncols is never written
+    // out): a conditional load makes hipcc branch around it and wait vmcnt(0), which kills the software pipeline.
+    int offA[MA], offB[NB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int tt = 4 * tk.ob + m;
-        int slot, hh, reg;
-        frag_coord(0, tt, c, slot, hh, reg);
-        okA[m] = tt < d.dz_tiles;
-        offA[m] = ((d.dz_slot0 + (okA[m] ? slot : 0)) * 64 + hh * 32 + kh) * 16 + reg;
-        const int tb = 4 * tk.ib + m;
-        int slotb, hb, regb;
-        const bool valid = frag_coord(xp.kind, tb, c, slotb, hb, regb);
-        okB[m] = tb < xp.ntiles && valid;
-        offB[m] = ((xp.slot0 + (okB[m] ? slotb : 0)) * 64 + hb * 32 + kh) * 16 + regb;
-    }
-    f32x16 acc[4][4];
+    for (int m = 0; m < MA; ++m) offA[m] = (d.dz_slot0 + 4 * tk.ob + m) * 1024 + c * 32 + 16 * kh;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < NB; ++n) offB[n] = (xp.slot0 + 4 * tk.ib + n) * 1024 + c * 32 + 16 * kh;
+    f32x16 acc[MA][NB];
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float rowsum[MA];
+#pragma unroll
+    for (int m = 0; m < MA; ++m) rowsum[m] = 0.f;
     const bool do_bias = (d.gb != nullptr) && tk.part == 0 && tk.ib == 0;
 
-    const long t_begin = (long)blockIdx.y * a.tiles_per_chunk;
-    long t_end = t_begin + a.tiles_per_chunk;
-    if (t_end > a.ntiles) t_end = a.ntiles;
+    if (t_begin >= t_end) return;
+    const float* __restrict__ zb = a.dz + (size_t)t_begin * a.z_slots * 1024;
+    const float* __restrict__ xb = a.acts + (size_t)t_begin * a.a_slots * 1024;
+    // Operand ring in units of QUADS (4 k-steps = one 16-byte load per operand and lane = 4*MA*NB MFMAs ~ 4000
+    // cycles for a 4x4 block). acts / dz stream from HBM (each slot is read by one workgroup only), so the ring runs
+    // PFQ = 2 quads ahead; it costs 4*(MA+NB) registers per stage.
+    constexpr int PFQ = 2;
+    f32x4 av[PFQ][MA], bv[PFQ][NB];
+#pragma unroll
+    for (int p = 0; p < PFQ; ++p) {
+#pragma unroll
+        for (int m = 0; m < MA; ++m) av[p][m] = *reinterpret_cast<const f32x4*>(zb + offA[m] + 4 * p);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bv[p][n] = *reinterpret_cast<const f32x4*>(xb + offB[n] + 4 * p);
+    }
     for (long ts = t_begin; ts < t_end; ++ts) {
-        const float* __restrict__ zb = a.dz + (size_t)ts * a.z_slots * 1024;
-        const float* __restrict__ xb = a.acts + (size_t)ts * a.a_slots * 1024;
-        float av[4], bv[4], an[4], bn[4];
+        const bool last_tile = ts + 1 >= t_end;
+        const float* __restrict__ zn = last_tile ? zb : zb + (size_t)a.z_slots * 1024;   // next tile (or a harmless re-read)
+        const float* __restrict__ xn = last_tile ? xb : xb + (size_t)a.a_slots * 1024;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { av[m] = okA[m] ? zb[offA[m]] : 0.f; bv[m] = okB[m] ? xb[offB[m]] : 0.f; }
+        for (int q = 0; q < 4; ++q) {
+            const int p = q % PFQ;
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            if (st + 1 < 16) {
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    an[m] = okA[m] ? zb[offA[m] + 32 * (st + 1)] : 0.f;
-                    bn[m] = okB[m] ? xb[offB[m] + 32 * (st + 1)] : 0.f;
+                for (int m = 0; m < MA; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p][m][e], bv[p][n][e], acc[m][n], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int m = 0; m < MA; ++m) rowsum[m] += av[p][m][e];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // refill this ring stage with quad q + PFQ (rolling into the next tile)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MA; ++m)
+                av[p][m] = *reinterpret_cast<const f32x4*>((q + PFQ < 4) ? zb + offA[m] + 4 * (q + PFQ) : zn + offA[m] + 4 * (q + PFQ - 4));
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-            if (do_bias) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) rowsum[m] += av[m];
-            }
-            if (st + 1 < 16) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { av[m] = an[m]; bv[m] = bn[m]; }
-            }
+            for (int n = 0; n < NB; ++n)
+                bv[p][n] = *reinterpret_cast<const f32x4*>((q + PFQ < 4) ? xb + offB[n] + 4 * (q + PFQ) : xn + offB[n] + 4 * (q + PFQ - 4));
+            __builtin_amdgcn_sched_barrier(0);
         }
+        zb = zn;
+        xb = xn;
     }
     // ---- add the block into the gradient: lane = column (input channel), registers = rows (output channels)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MA; ++m) {
         const int tt = 4 * tk.ob + m;
-        if (tt >= d.dz_tiles) continue;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int tb = 4 * tk.ib + n;
-            const int col = 32 * tb + c;
-            if (tb >= xp.ntiles || col >= xp.ncols) continue;
+        for (int n = 0; n < NB; ++n) {
+            const int col = 32 * (4 * tk.ib + n) + c;
+            if (col >= xp.ncols) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * tt + acc_channel(r, kh);
@@ -261,11 +256,50 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_kernel(WArgs a) {
     }
     if (do_bias) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float sres = rowsum[m] + __shfl_xor(rowsum[m], 32, 64);
+        for (int m = 0; m < MA; ++m) {
+            const float sres = rowsum[m] + __shfl_xor(rowsum[m], 32, 64);
             const int row = 32 * (4 * tk.ob + m) + c;
-            if (kh == 0 && 4 * tk.ob + m < d.dz_tiles && row >= d.row0 && row < d.row1) atomicAdd(d.gb + (row - d.row0), sres);
+            if (kh == 0 && row >= d.row0 && row < d.row1) atomicAdd(d.gb + (row - d.row0), sres);
         }
+    }
+}
+
+// Persistent grid (one workgroup per CU: 256 accumulator registers per lane leave room for one wave per SIMD).
+// The work "group g over sample tile t" costs group_cost[g] MFMAs per k-step; the flattened (group-major) sequence of
+// all such items is cut into gridDim.x equal-cost intervals, so every workgroup computes the same number of MFMAs
+// and adds its accumulators to the gradient once per (group, interval) segment - at most a handful of times.
+__global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_kernel(WArgs a) {
+    const int lane = threadIdx.x & 63;
+    // wave id made PROVABLY wave-uniform: tile bases then live in SGPRs and every access is scalar-base + 32-bit
+    // lane offset instead of a 64-bit VGPR pair per address (which spilled hundreds of registers)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long total = a.cum[a.ngroups];
+    const long lo = total / gridDim.x * blockIdx.x + (total % gridDim.x) * blockIdx.x / gridDim.x;
+    const long hi = total / gridDim.x * (blockIdx.x + 1) + (total % gridDim.x) * (blockIdx.x + 1) / gridDim.x;
+    for (int g = 0; g < a.ngroups; ++g) {
+        const long g0 = a.cum[g], g1 = a.cum[g + 1];
+        if (hi <= g0 || lo >= g1) continue;
+        const long c = a.group_cost[g];
+        const long s_ = (lo > g0 ? lo : g0) - g0, e_ = (hi < g1 ? hi : g1) - g0;
+        const long t_begin = (s_ + c - 1) / c, t_end = (e_ + c - 1) / c;     // same rounding at both ends: exact partition
+        const int task_id = g * 4 + wave;
+        if (task_id >= a.ntasks || t_begin >= t_end) continue;
+        const WTask tk = a.tasks[task_id];
+        const LinDesc& d = a.desc[tk.desc];
+        int ma = d.dz_tiles - 4 * tk.ob, nb = d.parts[tk.part].ntiles - 4 * tk.ib;
+        ma = ma > 4 ? 4 : ma;
+        nb = nb > 4 ? 4 : nb;
+        // wave-uniform dispatch on the block shape (the shapes a NeRF produces; anything else takes the padded path)
+        if (ma == 4 && nb == 4) dw_task<4, 4>(a, tk, lane, t_begin, t_end);
+        else if (ma == 4 && nb == 2) dw_task<4, 2>(a, tk, lane, t_begin, t_end);
+        else if (ma == 4 && nb == 1) dw_task<4, 1>(a, tk, lane, t_begin, t_end);
+        else if (ma == 1 && nb == 4) dw_task<1, 4>(a, tk, lane, t_begin, t_end);
+        else if (ma == 2 && nb == 2) dw_task<2, 2>(a, tk, lane, t_begin, t_end);
+        else if (ma == 2 && nb == 1) dw_task<2, 1>(a, tk, lane, t_begin, t_end);
+        else if (ma == 1 && nb == 2) dw_task<1, 2>(a, tk, lane, t_begin, t_end);
+        else if (ma == 1 && nb == 1) dw_task<1, 1>(a, tk, lane, t_begin, t_end);
+        else if (ma == 2 && nb == 4) dw_task<2, 4>(a, tk, lane, t_begin, t_end);
+        else dw_task<4, 4>(a, tk, lane, t_begin, t_end);   // unreachable for W in {64,128,256}
     }
 }
 
@@ -382,7 +416,7 @@ extern "C" int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts
         const bool emb = layer_has_emb(i, L.skip);
         const int in_f = (i == 0) ? kPtsCh : (emb ? W + kPtsCh : W);
         LinDesc& d = add(TL.z_Z0 + i * NT, NT, 0, W, in_f, (float*)g.pts_w[i], (float*)g.pts_b[i]);
-        if (emb) part(d, TL.a_E, 2, 1, 0, kPtsCh);
+        if (emb) part(d, TL.a_E, 2, 1, 0, kPtsCh);          // 63 encoding channels live in slots E0 E1 (channel 63 = 0)
         if (i > 0) part(d, TL.a_H1 + (i - 1) * NT, NT, 0, emb ? kPtsCh : 0, W);
     }
     NF_REQUIRE(g.feature_w && g.feature_b && g.views_w && g.views_b && g.alpha_w && g.alpha_b && g.rgb_w && g.rgb_b,
@@ -418,13 +452,30 @@ extern "C" int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts
                 }
     }
     a.ntasks = nt;
-    // enough (task, chunk) waves to fill the chip ~4x over; chunks of at least 16 tiles
-    const long want_chunks = (4L * cu_count() * 4 + nt - 1) / nt;
-    long tpc = (a.ntiles + want_chunks - 1) / want_chunks;
-    if (tpc < 16) tpc = 16;
-    a.tiles_per_chunk = (int)tpc;
-    const long nchunks = (a.ntiles + tpc - 1) / tpc;
-    const dim3 grid((unsigned)((nt + 3) / 4), (unsigned)nchunks), block(256);
+    // cost of a task = MFMAs per k-step = valid out tiles x valid in tiles; heaviest first, so the 4 waves of a
+    // workgroup carry equal work and the light tasks (encoding columns, heads) fill the tail
+    auto cost = [&](const WTask& t) {
+        const LinDesc& d = a.desc[t.desc];
+        int ma = d.dz_tiles - 4 * t.ob, nb = d.parts[t.part].ntiles - 4 * t.ib;
+        return (ma > 4 ? 4 : ma) * (nb > 4 ? 4 : nb);
+    };
+    for (int i = 1; i < nt; ++i) {      // insertion sort, stable
+        const WTask t = a.tasks[i];
+        int j = i - 1;
+        while (j >= 0 && cost(a.tasks[j]) < cost(t)) { a.tasks[j + 1] = a.tasks[j]; --j; }
+        a.tasks[j + 1] = t;
+    }
+    a.ngroups = (nt + 3) / 4;
+    a.cum[0] = 0;
+    for (int g = 0; g < a.ngroups; ++g) {
+        int c = 1;
+        for (int w = 0; w < 4 && g * 4 + w < nt; ++w) { const int cw = cost(a.tasks[g * 4 + w]); c = cw > c ? cw : c; }
+        a.group_cost[g] = c;
+        a.cum[g + 1] = a.cum[g] + (long)c * a.ntiles;
+    }
+    long wgs = cu_count();
+    if (wgs > a.cum[a.ngroups] / 16) wgs = a.cum[a.ngroups] / 16 > 0 ? a.cum[a.ngroups] / 16 : 1;   // tiny problems
+    const dim3 grid((unsigned)wgs), block(256);
     nerf_mlp_bwd_weights_kernel<<<grid, block, 0, as_stream(stream)>>>(a);
     NF_LAUNCHED("nerf_mlp_bwd_weights_kernel");
     return NERFAIL_OK;

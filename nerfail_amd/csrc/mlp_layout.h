@@ -54,11 +54,16 @@ static bool make_layout(int D, int W, int skip, MlpLayout& L) {
 }
 
 
-// ---- training buffers (fragment layout: [32-sample tile][slot][lane 0..63][16 registers]) ----------------
-// A "slot" is one 32-channel x 32-sample accumulator tile exactly as a wave holds it: lane l = (half h = l>>5,
-// sample j = l&31) stores its 16 registers (channels 32*tile + acc_channel(r, h)) as 64 contiguous bytes, so a
-// wave writes / reads 4 KB contiguous per slot.
-//   acts slots: E0 E1 (32 encoding k-steps of pts), V (16 encoding k-steps of dirs), H_1..H_D (NT each, post-ReLU
+// ---- training buffers: [32-sample tile][slot][32 channels][32 samples] ("channel-major tiles") -----------
+// A "slot" is one 32-channel x 32-sample tile, 4 KB, element (channel c, sample j) at float offset c*32 + j.
+//   * producers hold it in accumulator layout (lane = sample j + 32*half h, register r = channel acc_channel(r,h)):
+//     register r of a wave is two full 128-byte rows (channels acc_channel(r,0) and acc_channel(r,1)) -> one
+//     coalesced dword store / load instruction per register;
+//   * the weight-gradient kernel needs "channel on the lane, sample on the MFMA k index": with the k-step mapping
+//     (step st, half kh) <-> sample 16*kh + st, lane (c, kh) reads 16 CONTIGUOUS floats c*32 + 16*kh .. +15, i.e.
+//     four 16-byte loads cover all 16 k-steps of the tile.
+//   acts slots: E0 E1 (the 63 pts-encoding channels in RH:47-50 order, channel 63 = 0), V (27 dir-encoding
+//               channels, rest 0), H_1..H_D (NT each, post-ReLU
 //               outputs of pts_linears), F (NT, feature_linear output), HV (NT/2, post-ReLU views output)
 //   dz   slots: Z_0..Z_{D-1} (NT each, gradient w.r.t. the pre-activation of pts_linears[i]), ZF (NT), ZV (NT/2),
 //               ZR (1: d_raw, channels 0..3 = rgb, sigma)
@@ -119,6 +124,10 @@ __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __rest
         if (q + 1 < NQ) {
 #pragma unroll
             for (int t = 0; t < OT; ++t) nxt[t] = wp[((q + 1) * OT + t) * 64];
+            // Pin the software pipeline: nothing may be scheduled across this point, so the loads of quad q+1 stay
+            // AHEAD of the 4*OT MFMAs of quad q (under register pressure the scheduler otherwise sinks them next to
+            // their use and every quad waits vmcnt(0) on an exposed L2 round trip).
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -126,6 +135,7 @@ __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __rest
             for (int t = 0; t < OT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][e], bsel(q, e), acc[t], 0, 0, 0);
         if (q + 1 < NQ) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < OT; ++t) cur[t] = nxt[t];
         }
@@ -153,21 +163,55 @@ __device__ __forceinline__ void relu_to(f32x16 (&dst)[NT], const f32x16 (&src)[N
         for (int r = 0; r < 16; ++r) dst[t][r] = relu ? fmaxf(src[t][r], 0.f) : src[t][r];
 }
 
-// store / load NTILES accumulator tiles in fragment layout (64 B contiguous per lane and tile)
+// store / load accumulator-layout tiles to / from channel-major slots: one dword instruction per register = two
+// full 128-byte rows per wave instruction. Every address is "ONE per-lane pointer + compile-time constant":
+// acc_channel(r, h) = const(r) + 4h and enc_channel(s, h) = const(s) + 3h, so the half-dependent part lives in the
+// lane pointer and the rest folds into the instruction's immediate offset (computed per access, the addresses
+// otherwise get hoisted, spilled, and every store ends up behind a vmcnt(0)).
 template <int NTILES>
 __device__ __forceinline__ void store_tiles(float* __restrict__ base, const f32x16 (&a)[NTILES], int lane) {
+    float* __restrict__ lp = base + (lane >> 5) * 128 + (lane & 31);
 #pragma unroll
-    for (int t = 0; t < NTILES; ++t) {
-        f32x4* p = reinterpret_cast<f32x4*>(base + (t * 64 + lane) * 16);
+    for (int t = 0; t < NTILES; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) p[q] = (f32x4){a[t][4 * q], a[t][4 * q + 1], a[t][4 * q + 2], a[t][4 * q + 3]};
-    }
+        for (int r = 0; r < 16; ++r) lp[t * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = a[t][r];
 }
 __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(base + lane * 16);
-    const f32x4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-    return (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
-                    v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+    const float* __restrict__ lp = base + (lane >> 5) * 128 + (lane & 31);
+    f32x16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = lp[((r & 3) + 8 * (r >> 2)) * 32];
+    return v;
+}
+// positional-encoding k-step values (per lane: step s -> channel enc_channel(s, h)) <-> channel-major slots.
+// BANDS = 10 (pts: 63 channels in 2 slots) or 4 (dirs: 27 channels in 1 slot); padding channels are zero-filled so
+// the weight-gradient kernel never reads uninitialised memory.
+template <int BANDS, int NSTEPS>
+__device__ __forceinline__ void store_enc(float* __restrict__ base, const float (&e)[NSTEPS], int lane) {
+    const int h = lane >> 5, j = lane & 31;
+    float* __restrict__ lp3 = base + h * 96 + j;       // + 3h channels
+#pragma unroll
+    for (int s = 0; s < 3 * BANDS; ++s) lp3[(3 + 6 * (s / 3) + (s % 3)) * 32] = e[s];
+    base[h * 32 + j] = e[3 * BANDS];                   // x | y  (channels 0, 1)
+    constexpr int nch = 3 + 6 * BANDS, cap = ((nch + 31) / 32) * 32;
+    // half 0: z (channel 2) and the even padding channels; half 1: the odd padding channels
+    float* __restrict__ lpz = base + j;
+    if (h == 0) lpz[2 * 32] = e[3 * BANDS + 1];
+#pragma unroll
+    for (int c = nch; c < cap; ++c)
+        if (((c - nch) & 1) == h) lpz[c * 32] = 0.f;
+}
+template <int BANDS, int NSTEPS>
+__device__ __forceinline__ void load_enc(const float* __restrict__ base, float (&e)[NSTEPS], int lane) {
+    const int h = lane >> 5, j = lane & 31;
+    const float* __restrict__ lp3 = base + h * 96 + j;
+#pragma unroll
+    for (int s = 0; s < 3 * BANDS; ++s) e[s] = lp3[(3 + 6 * (s / 3) + (s % 3)) * 32];
+    e[3 * BANDS] = base[h * 32 + j];
+    const float z = base[2 * 32 + j];
+    e[3 * BANDS + 1] = h ? 0.f : z;
+#pragma unroll
+    for (int s = 3 * BANDS + 2; s < NSTEPS; ++s) e[s] = 0.f;
 }
 
 }  // namespace nerfail
