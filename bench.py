@@ -118,6 +118,26 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024):
                          'note': 'whole step incl. sampling, compositing, Adam and host launch gaps; 3x forward FLOPs'}}
 
 
+def knn_bench(dev, reps=2):
+    """8-NN index build of ONE view (create_index_and_dist.py:126-145): 640 000 queries (the view's pts_max) against the
+    1 920 000-point set of 3 base views; synthetic shell points. Exact (d2, index) ordering."""
+    from nerfail_amd.create_index_and_dist import index_and_dist
+    S = torch.from_numpy(synth.sphere_shell_points(3 * H * W, seed=0)).to(dev)
+    Q = torch.from_numpy(synth.sphere_shell_points(H * W, seed=1).reshape(H, W, 3)).to(dev)
+    out = index_and_dist(Q, S)
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(reps):
+        out = index_and_dist(Q, S)
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / reps
+    pairs = float(H * W) * float(3 * H * W)
+    return {'views_per_sec': 1.0 / dt, 'ms_per_view': dt * 1e3, 'queries_per_sec': H * W / dt,
+            'brute_force_equivalent_pairs_per_sec': pairs / dt,
+            'note': 'brute-force-equivalent pair rate; 8 flops per pair without FMA would be bound by %.1f TFLOP/s vector f32'
+                    % (PEAK_F32_MFMA_TFLOPS / 2)}
+
+
 def victim_cnn(num_classes=8):
     """Stand-in victim with the shape of the reference's 800x800 classifier (model/MyModel.py:5-52: seven
     3x3 conv + ReLU + 2x2 max-pool stages 3-32-64-128-256-256-128-64, then 1024-512-classes). Stock PyTorch
@@ -194,8 +214,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-attack', action='store_true', help='skip the extra train / attack sections')
-    ap.add_argument('--sections', default='render,train,attack',
-                    help='comma list of render,train,attack (profiling aid; the JSON line needs render)')
+    ap.add_argument('--sections', default='render,train,attack,knn',
+                    help='comma list of render,train,attack,knn (profiling aid; the JSON line needs render)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -218,6 +238,8 @@ def main():
             out['train'] = train_bench(dev)
         if 'attack' in sections:
             out['attack'] = attack_bench(dev)
+        if 'knn' in sections:
+            out['knn'] = knn_bench(dev)
         print(json.dumps(out), flush=True)
         return
 
@@ -306,6 +328,8 @@ def main():
                 line['train'] = train_bench(dev)
             if 'attack' in sections:
                 line['attack'] = attack_bench(dev)
+            if 'knn' in sections:
+                line['knn'] = knn_bench(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

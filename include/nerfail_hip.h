@@ -169,6 +169,14 @@ int nerfail_composite_bwd(const float* raw, const float* z_vals, const float* ra
 int nerfail_knn8(const float* queries, int64_t n_queries, const float* points, int64_t n_points,
                  float* dist, float* idx_f32, int32_t* idx_i32, void* stream);
 
+/* Same result, bit for bit, through a uniform grid (cell sort + shell expansion with a conservative termination
+ * bound): ~1000x less work than the brute-force scan at 1.92 M points. workspace: scratch of
+ * nerfail_knn8_grid_workspace_bytes(n_points) bytes (0 = unsupported size). */
+size_t nerfail_knn8_grid_workspace_bytes(int64_t n_points);
+int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* points, int64_t n_points,
+                      float* dist, float* idx_f32, int32_t* idx_i32, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 /* ------------------------------------------------------------------ gauss path (K9-K12) --- */
 
 /* create_gauss_w.forward, GN:169-186 (driver DW:82-97): dist_and_index[B,2,P,8] -> out[B,2,P,8]

@@ -60,6 +60,8 @@ SIGNATURES = {
     'nerfail_composite': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_composite_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_knn8': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    'nerfail_knn8_grid_workspace_bytes': (ctypes.c_size_t, [c_i64]),
+    'nerfail_knn8_grid': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),

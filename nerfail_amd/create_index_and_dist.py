@@ -18,24 +18,40 @@ from . import _lib
 from .run_nerf_helpers import _cuda
 
 
-def knn8(queries, points, want_int=False):
-    """queries [...,3], points [M,3] -> (dist [...,8] ascending, idx [...,8] float32 | int32)."""
+def knn8(queries, points, want_int=False, method='auto'):
+    """queries [...,3], points [M,3] -> (dist [...,8] ascending, idx [...,8] float32 | int32).
+
+    method: 'grid' (uniform-grid search), 'brute' (streaming scan) or 'auto' (grid from 4096 points up). Both produce
+    the same bits: the ordering key is (d2, index) with d2 = ((dx*dx + dy*dy) + dz*dz) in float32 (oracle/knn.py)."""
     dev = _cuda()
+    lib = _lib.load()
     q = _lib.f32c(queries, dev)
     p = _lib.f32c(points, dev).reshape(-1, 3)
     lead = q.shape[:-1]
     q2 = q.reshape(-1, 3)
     dist = torch.empty((q2.shape[0], 8), dtype=torch.float32, device=dev)
     idx = torch.empty((q2.shape[0], 8), dtype=torch.int32 if want_int else torch.float32, device=dev)
-    _lib.check(_lib.load().nerfail_knn8(_lib.dev(q2, 'queries'), q2.shape[0], _lib.dev(p, 'points'), p.shape[0],
-                                        _lib.dev(dist), None if want_int else _lib.dev(idx),
-                                        _lib.dev(idx) if want_int else None, _lib.stream()))
+    idx_f, idx_i = (None, _lib.dev(idx)) if want_int else (_lib.dev(idx), None)
+    if method == 'auto':
+        method = 'grid' if p.shape[0] >= 4096 else 'brute'
+    if method == 'grid':
+        nbytes = lib.nerfail_knn8_grid_workspace_bytes(p.shape[0])
+        if nbytes == 0:
+            raise _lib.NerfailError('nerfail_knn8_grid: unsupported point count %d (need 8 <= M < 2^24)' % p.shape[0])
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.nerfail_knn8_grid(_lib.dev(q2, 'queries'), q2.shape[0], _lib.dev(p, 'points'), p.shape[0],
+                                         _lib.dev(dist), idx_f, idx_i, _lib.dev(ws), nbytes, _lib.stream()))
+    elif method == 'brute':
+        _lib.check(lib.nerfail_knn8(_lib.dev(q2, 'queries'), q2.shape[0], _lib.dev(p, 'points'), p.shape[0],
+                                    _lib.dev(dist), idx_f, idx_i, _lib.stream()))
+    else:
+        raise ValueError('method must be auto, grid or brute')
     return dist.reshape(tuple(lead) + (8,)), idx.reshape(tuple(lead) + (8,))
 
 
-def index_and_dist(view_pts, point_set):
+def index_and_dist(view_pts, point_set, method='auto'):
     """One view: pts_max [H,W,3] vs point set [M,3] -> float32 [2,H,W,8] exactly as saved at CI:148-163."""
-    d, i = knn8(view_pts, point_set)
+    d, i = knn8(view_pts, point_set, method=method)
     return torch.stack([d, i], 0)
 
 

@@ -1,0 +1,272 @@
+// K8, accelerated: exact 8-nearest-neighbour build over a uniform grid (same result, bit for bit, as the brute-force
+// kernel in knn.hip and as oracle/knn.py). Replaces create_index_and_dist.py:126-145.
+//
+//   build:  bounding box of the point set -> G^3 cells (G ~ M^(1/3)) -> cell id per point -> stable radix sort of
+//           (cell, point index) pairs (rocPRIM via hipCUB) -> points gathered into cell order as float4 (x, y, z,
+//           original index) + cell_start[G^3 + 1] by binary search.
+//   query:  one thread per query; visit the cells of Chebyshev shell R = 0, 1, 2, ... around the query's cell,
+//           keeping the 8 smallest keys (d2, index) in registers (d2 = ((dx*dx + dy*dy) + dz*dz), float32, no FMA,
+//           exactly the brute-force arithmetic; lexicographic insertion because cells are not visited in index order).
+//           After shell R every unvisited point lies outside the (2R+1)^3 block, i.e. at least `bound` away, where
+//           bound = distance from the query to the nearest block face that still has cells behind it. The search
+//           stops once the current 8th key satisfies  d2_8 < (0.999 * bound)^2  (strict, with a safety factor far
+//           above float32 rounding), so no unvisited point can enter the result or tie with it.
+// Points are image pixels' surface points: on a G ~ 124 grid shell 1 (27 cells, ~10 occupied, ~40 points each)
+// normally finishes the query, ~1000x less work than the 1.92 M-point brute-force scan.
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace nerfail {
+
+struct Grid {
+    float ox, oy, oz;     // origin (bbox min)
+    float cs, inv_cs;     // cell size (cubic cells)
+    int G;
+};
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ pts, long n, float* __restrict__ mm /*6: min xyz, max xyz*/) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[3 * i + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = wave_min(lo[a]);
+        hi[a] = wave_max(hi[a]);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // float atomic min / max through the ordered-integer trick
+            if (lo[a] >= 0.f) atomicMin(reinterpret_cast<int*>(mm + a), __float_as_int(lo[a]));
+            else atomicMax(reinterpret_cast<unsigned*>(mm + a), __float_as_uint(lo[a]));
+            if (hi[a] >= 0.f) atomicMax(reinterpret_cast<int*>(mm + 3 + a), __float_as_int(hi[a]));
+            else atomicMin(reinterpret_cast<unsigned*>(mm + 3 + a), __float_as_uint(hi[a]));
+        }
+    }
+}
+
+__global__ void bbox_init_kernel(float* mm) {
+    if (threadIdx.x < 3) mm[threadIdx.x] = INFINITY;
+    else if (threadIdx.x < 6) mm[threadIdx.x] = -INFINITY;
+}
+
+// grid parameters from the bbox (device side, so the build never synchronises with the host)
+__global__ void grid_params_kernel(const float* __restrict__ mm, int G, Grid* __restrict__ g) {
+    if (threadIdx.x != 0) return;
+    float ext = fmaxf(fmaxf(mm[3] - mm[0], mm[4] - mm[1]), mm[5] - mm[2]);
+    if (!(ext > 0.f)) ext = 1.f;
+    const float cs = ext * 1.0001f / (float)G;
+    g->ox = mm[0]; g->oy = mm[1]; g->oz = mm[2];
+    g->cs = cs; g->inv_cs = 1.0f / cs; g->G = G;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_cs, int G) {
+    int c = (int)floorf((v - o) * inv_cs);
+    return c < 0 ? 0 : (c >= G ? G - 1 : c);
+}
+
+__global__ __launch_bounds__(256) void cell_ids_kernel(const float* __restrict__ pts, long n, const Grid* __restrict__ gp,
+                                                       unsigned* __restrict__ keys, int* __restrict__ vals) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Grid g = *gp;
+    const int cx = cell_coord(pts[3 * i], g.ox, g.inv_cs, g.G), cy = cell_coord(pts[3 * i + 1], g.oy, g.inv_cs, g.G),
+              cz = cell_coord(pts[3 * i + 2], g.oz, g.inv_cs, g.G);
+    keys[i] = (unsigned)((cz * g.G + cy) * g.G + cx);
+    vals[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const float* __restrict__ pts, const int* __restrict__ order,
+                                                            long n, float4* __restrict__ sorted) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int src = order[i];
+    sorted[i] = make_float4(pts[3 * (long)src], pts[3 * (long)src + 1], pts[3 * (long)src + 2], __int_as_float(src));
+}
+
+__global__ __launch_bounds__(256) void cell_start_kernel(const unsigned* __restrict__ keys_sorted, long n, long ncells,
+                                                         int* __restrict__ cell_start) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > ncells) return;
+    long lo = 0, hi = n;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if ((long)keys_sorted[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    cell_start[c] = (int)lo;
+}
+
+struct Top8L {
+    float d[8];
+    int i[8];
+};
+
+__device__ __forceinline__ bool key_less(float d2, int idx, float d, int i) { return d2 < d || (d2 == d && idx < i); }
+
+__device__ __forceinline__ void top8_insert_lex(Top8L& t, float d2, int idx) {
+#pragma unroll
+    for (int k = 7; k >= 1; --k) {
+        const bool shift = key_less(d2, idx, t.d[k - 1], t.i[k - 1]);
+        const bool here = !shift && key_less(d2, idx, t.d[k], t.i[k]);
+        const float nd = shift ? t.d[k - 1] : (here ? d2 : t.d[k]);
+        const int ni = shift ? t.i[k - 1] : (here ? idx : t.i[k]);
+        t.d[k] = nd; t.i[k] = ni;
+    }
+    if (key_less(d2, idx, t.d[0], t.i[0])) { t.d[0] = d2; t.i[0] = idx; }
+}
+
+__global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict__ queries, long nq, const Grid* __restrict__ gp,
+                                                        const float4* __restrict__ sorted, const int* __restrict__ cell_start,
+                                                        float* __restrict__ dist, float* __restrict__ idx_f,
+                                                        int* __restrict__ idx_i) {
+    const long qi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    const Grid g = *gp;
+    const int G = g.G;
+    const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+    const int cx = cell_coord(qx, g.ox, g.inv_cs, G), cy = cell_coord(qy, g.oy, g.inv_cs, G), cz = cell_coord(qz, g.oz, g.inv_cs, G);
+    Top8L top;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
+
+    for (int R = 0; R < G; ++R) {
+        const int z0 = max(cz - R, 0), z1 = min(cz + R, G - 1);
+        const int y0 = max(cy - R, 0), y1 = min(cy + R, G - 1);
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, G - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const bool zface = (z == cz - R) || (z == cz + R);
+            for (int y = y0; y <= y1; ++y) {
+                const bool yface = zface || (y == cy - R) || (y == cy + R);
+                // on a z / y face of the shell the whole x row belongs to it (contiguous cells -> one point range);
+                // otherwise only the two end cells x = cx -+ R do
+                const long row = ((long)z * G + y) * G;
+                if (yface) {
+                    const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                    for (int p = b; p < e; ++p) {
+                        const float4 pt = sorted[p];
+                        const float dx = __fsub_rn(qx, pt.x), dy = __fsub_rn(qy, pt.y), dz = __fsub_rn(qz, pt.z);
+                        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                        const int id = __float_as_int(pt.w);
+                        if (key_less(d2, id, top.d[7], top.i[7])) top8_insert_lex(top, d2, id);
+                    }
+                } else {
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        const int x = side ? cx + R : cx - R;
+                        if (x < 0 || x >= G || (side == 1 && R == 0)) continue;
+                        const int b = cell_start[row + x], e = cell_start[row + x + 1];
+                        for (int p = b; p < e; ++p) {
+                            const float4 pt = sorted[p];
+                            const float dx = __fsub_rn(qx, pt.x), dy = __fsub_rn(qy, pt.y), dz = __fsub_rn(qz, pt.z);
+                            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                            const int id = __float_as_int(pt.w);
+                            if (key_less(d2, id, top.d[7], top.i[7])) top8_insert_lex(top, d2, id);
+                        }
+                    }
+                }
+            }
+        }
+        // every unvisited point is outside the block [c-R, c+R]^3: lower bound of its distance to the query
+        float bound = INFINITY;
+        if (cx - R > 0) bound = fminf(bound, qx - (g.ox + (float)(cx - R) * g.cs));
+        if (cx + R < G - 1) bound = fminf(bound, (g.ox + (float)(cx + R + 1) * g.cs) - qx);
+        if (cy - R > 0) bound = fminf(bound, qy - (g.oy + (float)(cy - R) * g.cs));
+        if (cy + R < G - 1) bound = fminf(bound, (g.oy + (float)(cy + R + 1) * g.cs) - qy);
+        if (cz - R > 0) bound = fminf(bound, qz - (g.oz + (float)(cz - R) * g.cs));
+        if (cz + R < G - 1) bound = fminf(bound, (g.oz + (float)(cz + R + 1) * g.cs) - qz);
+        if (bound == INFINITY) break;                       // the block covers the whole grid
+        if (bound > 0.f) {
+            const float sb = 0.999f * bound;
+            if (top.d[7] < sb * sb) break;                  // strict: nothing unvisited can enter or tie
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        dist[8 * qi + k] = sqrt_rn(top.d[k]);
+        if (idx_f != nullptr) idx_f[8 * qi + k] = (float)top.i[k];
+        if (idx_i != nullptr) idx_i[8 * qi + k] = top.i[k];
+    }
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int grid_dim_for(long n) {
+    int G = (int)lround(cbrt((double)n));
+    if (G < 4) G = 4;
+    if (G > 256) G = 256;
+    return G;
+}
+
+static size_t knn_cub_temp(long n) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+                                       (int*)nullptr, (int)n, 0, 32, (hipStream_t) nullptr);
+    return bytes;
+}
+
+}  // namespace nerfail
+
+using namespace nerfail;
+
+extern "C" size_t nerfail_knn8_grid_workspace_bytes(int64_t n_points) {
+    if (n_points < NERFAIL_KNN || n_points >= (1 << 24)) return 0;
+    const int G = grid_dim_for(n_points);
+    const size_t ncells = (size_t)G * G * G;
+    return al256(256) /* bbox + Grid */ + 4 * al256((size_t)n_points * 4) /* keys in/out, vals in/out */ +
+           al256((size_t)n_points * 16) /* sorted float4 */ + al256((ncells + 1) * 4) + al256(knn_cub_temp(n_points));
+}
+
+extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* points, int64_t n_points, float* dist,
+                                 float* idx_f32, int32_t* idx_i32, void* workspace, size_t workspace_bytes, void* stream) {
+    NF_REQUIRE(n_queries >= 0, "n_queries is negative");
+    NF_REQUIRE(n_points >= NERFAIL_KNN, "need at least 8 points");
+    NF_REQUIRE(n_points < (1 << 24), "n_points must be < 2^24 (indices are stored as float32, CI:148-163)");
+    if (n_queries == 0) return NERFAIL_OK;
+    NF_REQUIRE(queries != nullptr && points != nullptr && dist != nullptr, "NULL pointer");
+    NF_REQUIRE(idx_f32 != nullptr || idx_i32 != nullptr, "need idx_f32 or idx_i32");
+    NF_REQUIRE(workspace != nullptr && workspace_bytes >= nerfail_knn8_grid_workspace_bytes(n_points),
+               "workspace too small (nerfail_knn8_grid_workspace_bytes)");
+    hipStream_t s = as_stream(stream);
+    const int G = grid_dim_for(n_points);
+    const long ncells = (long)G * G * G, n = n_points;
+    char* ws = (char*)workspace;
+    float* mm = (float*)ws;
+    Grid* gp = (Grid*)(ws + 64);
+    ws += al256(256);
+    const size_t seg = al256((size_t)n * 4);
+    unsigned* keys_in = (unsigned*)ws; unsigned* keys_out = (unsigned*)(ws + seg);
+    int* vals_in = (int*)(ws + 2 * seg); int* vals_out = (int*)(ws + 3 * seg);
+    ws += 4 * seg;
+    float4* sorted = (float4*)ws; ws += al256((size_t)n * 16);
+    int* cell_start = (int*)ws; ws += al256((size_t)(ncells + 1) * 4);
+    void* temp = ws;
+    size_t temp_bytes = knn_cub_temp(n);
+
+    bbox_init_kernel<<<dim3(1), dim3(64), 0, s>>>(mm);
+    NF_LAUNCHED("bbox_init_kernel");
+    bbox_kernel<<<dim3(256), dim3(256), 0, s>>>(points, n, mm);
+    NF_LAUNCHED("bbox_kernel");
+    grid_params_kernel<<<dim3(1), dim3(64), 0, s>>>(mm, G, gp);
+    NF_LAUNCHED("grid_params_kernel");
+    cell_ids_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(points, n, gp, keys_in, vals_in);
+    NF_LAUNCHED("cell_ids_kernel");
+    int bits = 1;
+    while ((1L << bits) < ncells) ++bits;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, bits, s);
+    if (e != hipSuccess) return hip_fail(e, "hipcub::DeviceRadixSort::SortPairs");
+    gather_sorted_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(points, vals_out, n, sorted);
+    NF_LAUNCHED("gather_sorted_kernel");
+    cell_start_kernel<<<dim3((unsigned)((ncells + 1 + 255) / 256)), dim3(256), 0, s>>>(keys_out, n, ncells, cell_start);
+    NF_LAUNCHED("cell_start_kernel");
+    knn8_grid_kernel<<<dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s>>>(queries, n_queries, gp, sorted, cell_start,
+                                                                                  dist, idx_f32, idx_i32);
+    NF_LAUNCHED("knn8_grid_kernel");
+    return NERFAIL_OK;
+}

@@ -19,10 +19,11 @@ def _cases(golden):
 def test_knn_bit_exact_vs_oracle(golden):
     from nerfail_amd.create_index_and_dist import knn8, index_and_dist
     for Q, S in _cases(golden):
-        d, i = knn8(T(Q), T(S), want_int=True)
         od, oi = OK.knn8(Q.reshape(-1, 3), S)
-        assert np.array_equal(N(i).reshape(-1, 8), oi)
-        assert np.array_equal(N(d).reshape(-1, 8), od)
+        for method in ('brute', 'grid'):
+            d, i = knn8(T(Q), T(S), want_int=True, method=method)
+            assert np.array_equal(N(i).reshape(-1, 8), oi), method
+            assert np.array_equal(N(d).reshape(-1, 8), od), method
         out = N(index_and_dist(T(Q), T(S)))
         assert out.shape == (2,) + Q.shape[:2] + (8,) and out.dtype == np.float32
         assert np.array_equal(out, OK.index_and_dist(Q, S))
@@ -34,9 +35,10 @@ def test_knn_ragged_sizes():
         S = synth.sphere_shell_points(npnt, seed=nq)
         Q = synth.sphere_shell_points(nq, seed=npnt + 1)
         S[npnt // 2] = S[0]                                   # a tie pair
-        d, i = knn8(T(Q), T(S), want_int=True)
         od, oi = OK.knn8(Q, S)
-        assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
+        for method in ('brute', 'grid'):
+            d, i = knn8(T(Q), T(S), want_int=True, method=method)
+            assert np.array_equal(N(i), oi) and np.array_equal(N(d), od), method
 
 
 def test_knn_rejects_too_few_points():
@@ -44,3 +46,39 @@ def test_knn_rejects_too_few_points():
     from nerfail_amd._lib import NerfailError
     with pytest.raises(NerfailError):
         knn8(T(np.zeros((4, 3), np.float32)), T(np.zeros((7, 3), np.float32)))
+
+
+def test_knn_grid_adversarial_inputs_match_brute_force():
+    """Grid search == brute force bit for bit on inputs that stress the termination bound and the cell logic:
+    queries far outside the bounding box, a degenerate (planar / collinear) point set, heavy duplicates, one dense
+    cluster plus far outliers, and the full-size shape (1.92 M points) on a query subset."""
+    from nerfail_amd.create_index_and_dist import knn8
+    rs = np.random.RandomState(7)
+    cases = []
+    S = synth.sphere_shell_points(50000, seed=1)
+    cases.append((np.concatenate([rs.uniform(-5, 5, (300, 3)), rs.uniform(-1, 1, (300, 3))]).astype(np.float32), S))
+    plane = rs.uniform(-1, 1, (30000, 3)).astype(np.float32)
+    plane[:, 2] = 0.25
+    cases.append((rs.uniform(-1, 1, (500, 3)).astype(np.float32), plane))
+    line = np.zeros((20000, 3), np.float32)
+    line[:, 0] = rs.uniform(-1, 1, 20000)
+    cases.append((rs.uniform(-1, 1, (300, 3)).astype(np.float32), line))
+    dup = np.repeat(rs.uniform(-1, 1, (700, 3)).astype(np.float32), 12, axis=0)          # every point 12x
+    cases.append((dup[::7].copy(), dup))
+    clus = np.concatenate([rs.normal(scale=1e-3, size=(40000, 3)), rs.uniform(-50, 50, (64, 3))]).astype(np.float32)
+    cases.append((np.concatenate([rs.normal(scale=1e-3, size=(400, 3)), rs.uniform(-50, 50, (100, 3))]).astype(np.float32), clus))
+    for Q, P in cases:
+        db, ib = knn8(T(Q), T(P), want_int=True, method='brute')
+        dg, ig = knn8(T(Q), T(P), want_int=True, method='grid')
+        assert torch_equal(ib, ig) and torch_equal(db, dg)
+    # full-size point set (3 x 800 x 800), 4096 queries
+    P = synth.sphere_shell_points(3 * 800 * 800, seed=0)
+    Q = synth.sphere_shell_points(4096, seed=1)
+    db, ib = knn8(T(Q), T(P), want_int=True, method='brute')
+    dg, ig = knn8(T(Q), T(P), want_int=True, method='grid')
+    assert torch_equal(ib, ig) and torch_equal(db, dg)
+
+
+def torch_equal(a, b):
+    import torch
+    return torch.equal(a, b)
