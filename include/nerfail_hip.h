@@ -201,7 +201,7 @@ int nerfail_gauss_bwd(const float* weight_and_index, const float* ori_img, const
 /* Deterministic form of the same backward. The index map of a view is static, so its inverse (for each
  * row of the perturbation table, the contributions (view b, pixel p, neighbour k) that gather from it, in
  * ascending (b*P+p)*8+k order) is built once and reused by every attack epoch:
- *   row_ptr[B*Ns+1] int32, contrib[B*P*8] int32 (contribution id), w_sorted[B*P*8] (its weight).
+ *   row_ptr[Ns+1] int32, contrib[B*P*8] int32 (contribution id), w_sorted[B*P*8] (its weight).
  * workspace: nerfail_gauss_csr_workspace_bytes() bytes of scratch (0 = sizes unsupported). */
 size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64_t P);
 int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns, int64_t B, int64_t P, int32_t* row_ptr,

@@ -14,17 +14,17 @@ from .run_nerf_helpers import _cuda
 
 class GaussCSR:
     """Inverted index of a batch of views' 8-NN maps (built once per batch tensor, reused by every backward):
-    row_ptr [B*Ns+1] int32, contrib [B*P*8] int32, w_sorted [B*P*8] float32 (nerfail_gauss_csr_build)."""
+    row_ptr [Ns+1] int32, contrib [B*P*8] int32, w_sorted [B*P*8] float32 (nerfail_gauss_csr_build)."""
 
     def __init__(self, wi, Ns):
         lib = _lib.load()
         B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
         nbytes = lib.nerfail_gauss_csr_workspace_bytes(Ns, B, P)
         if nbytes == 0:
-            raise ValueError('batch too large for the 32-bit inverted index (B*P*8 < 2^31, B*Ns < 2^32)')
+            raise ValueError('batch too large for the 32-bit inverted index (B*P*8 < 2^31)')
         dev = wi.device
         self.Ns, self.B, self.P = Ns, B, P
-        self.row_ptr = torch.empty((B * Ns + 1,), dtype=torch.int32, device=dev)
+        self.row_ptr = torch.empty((Ns + 1,), dtype=torch.int32, device=dev)
         self.contrib = torch.empty((B * P * 8,), dtype=torch.int32, device=dev)
         self.w_sorted = torch.empty((B * P * 8,), dtype=torch.float32, device=dev)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)

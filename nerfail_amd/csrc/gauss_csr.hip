@@ -24,11 +24,11 @@ __global__ __launch_bounds__(256) void csr_keys_kernel(const float* __restrict__
     const long b = bp / P, p = bp - b * P;
     long j = (long)wi[((b * 2 + 1) * P + p) * 8 + k];
     j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
-    keys[g] = (unsigned)(b * Ns + j);
+    keys[g] = (unsigned)j;          // one list per destination row over the WHOLE batch (ids ascending inside: b, p, k)
     vals[g] = (int)g;
 }
 
-// row_ptr[r] = first sorted position whose key >= r (r in [0, B*Ns]); weights gathered into sorted order
+// row_ptr[r] = first sorted position whose key >= r (r in [0, Ns]); weights gathered into sorted order
 __global__ __launch_bounds__(256) void csr_rows_kernel(const unsigned* __restrict__ keys_sorted, long n, long rows,
                                                        int* __restrict__ row_ptr) {
     const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -87,22 +87,65 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __r
     g_out[g] = gx;
 }
 
-// pass 2: one thread per destination row; views in ascending order, contributions in ascending id order
+// pass 2: one thread per destination row, contributions of the whole batch in ascending id order (fixed order =>
+// bitwise reproducible).
+//   * The 64 rows of a wave are one CONTIGUOUS range of the index arrays (~21 entries per row): the wave first copies
+//     that range into LDS with coalesced loads (lane i takes entries i, i+64, ...). Walking the rows straight from
+//     global memory instead makes every lane stream its own 84-byte-strided slice: ~43 cache lines per wave load, L1
+//     thrash, ~30x read amplification.
+//   * The trip count is WAVE-UNIFORM (max row length of the wave) and all loads are unconditional (clamped index,
+//     weight 0 past the row's end), so the 4x unrolled loop keeps the 16-byte gathers of 4 contributions in flight.
+constexpr int kRowCap = 2048;    // index entries staged per wave (16 KB of LDS); longer ranges take the direct path
+
 __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __restrict__ row_ptr, const int* __restrict__ contrib,
                                                                const float* __restrict__ w_sorted,
-                                                               const float4* __restrict__ g_pix, long Ns, long B,
+                                                               const float4* __restrict__ g_pix, long Ns,
                                                                int accumulate, float4* __restrict__ grad_spatial) {
+    __shared__ int s_id[4][kRowCap];
+    __shared__ float s_w[4][kRowCap];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= Ns) return;
+    const long j0 = j - lane;                      // first row of this wave
+    if (j0 >= Ns) return;                          // whole wave out of range
+    const long jc = j < Ns ? j : Ns - 1;
+    const int c0 = row_ptr[jc];
+    const int len = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
+    const int base = __shfl(c0, 0, 64);
+    const long jl = (j0 + 64 < Ns) ? j0 + 64 : Ns;
+    const int n = row_ptr[jl] - base;              // entries of the wave's 64 rows (wave-uniform)
+    int maxlen = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long b = 0; b < B; ++b) {
-        const int c0 = row_ptr[b * Ns + j], c1 = row_ptr[b * Ns + j + 1];
-        for (int c = c0; c < c1; ++c) {
-            const float w = w_sorted[c];
-            const float4 g = g_pix[contrib[c] >> 3];
-            acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+    const bool staged = n <= kRowCap;
+    if (staged) {
+        for (int i = lane; i < n; i += 64) { s_id[wv][i] = contrib[base + i]; s_w[wv][i] = w_sorted[base + i]; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes before its reads
+    }
+    const int r0 = c0 - base;
+    for (int k = 0; k < maxlen; k += 4) {
+        int id[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = k + u < len;
+            const int c = ok ? r0 + k + u : 0;
+            if (staged) { id[u] = s_id[wv][c]; w[u] = s_w[wv][c]; }
+            else { id[u] = contrib[base + c]; w[u] = w_sorted[base + c]; }
+            if (!ok) w[u] = 0.f;
+        }
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = g_pix[id[u] >> 3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k + u < len) {                     // keeps 0 * inf / NaN of a foreign row out of the sum
+                acc.x += w[u] * g[u].x; acc.y += w[u] * g[u].y; acc.z += w[u] * g[u].z; acc.w += w[u] * g[u].w;
+            }
         }
     }
+    if (j >= Ns) return;
     if (accumulate) {
         const float4 old = grad_spatial[j];
         acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
@@ -126,7 +169,7 @@ using namespace nerfail;
 extern "C" size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64_t P) {
     if (Ns <= 0 || B <= 0 || P <= 0) return 0;
     const long n = B * P * 8;
-    if (n >= (1L << 31) || B * Ns >= (1L << 32) - 1) return 0;
+    if (n >= (1L << 31) || Ns >= (1L << 31) - 1) return 0;
     return 3 * align256((size_t)n * 4) + align256(cub_temp_bytes(n));
 }
 
@@ -135,7 +178,7 @@ extern "C" int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns
                                        void* stream) {
     NF_REQUIRE(Ns > 0 && B > 0 && P > 0, "bad sizes");
     const long n = B * P * 8;
-    NF_REQUIRE(n < (1L << 31) && B * Ns < (1L << 32) - 1, "batch too large for 32-bit CSR ids");
+    NF_REQUIRE(n < (1L << 31) && Ns < (1L << 31) - 1, "batch too large for 32-bit CSR ids");
     NF_REQUIRE(weight_and_index && row_ptr && contrib && w_sorted && workspace, "NULL pointer");
     const size_t need = nerfail_gauss_csr_workspace_bytes(Ns, B, P);
     NF_REQUIRE(workspace_bytes >= need, "workspace too small (nerfail_gauss_csr_workspace_bytes)");
@@ -150,10 +193,10 @@ extern "C" int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns
     csr_keys_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(weight_and_index, Ns, B, P, keys_in, vals_in);
     NF_LAUNCHED("csr_keys_kernel");
     int bits = 1;
-    while ((1L << bits) < B * Ns + 1) ++bits;     // sort only the significant key bits (stable LSD radix)
+    while ((1L << bits) < Ns + 1) ++bits;         // sort only the significant key bits (stable LSD radix)
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, contrib, (int)n, 0, bits, s);
     if (e != hipSuccess) return hip_fail(e, "hipcub::DeviceRadixSort::SortPairs");
-    const long rows = B * Ns;
+    const long rows = Ns;
     csr_rows_kernel<<<dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, s>>>(keys_out, n, rows, row_ptr);
     NF_LAUNCHED("csr_rows_kernel");
     csr_weights_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(weight_and_index, contrib, n, P, w_sorted);
@@ -174,7 +217,7 @@ extern "C" int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const
         (float4*)pixel_grad_scratch);
     NF_LAUNCHED("gauss_pixel_grad_kernel");
     gauss_row_reduce_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(
-        row_ptr, contrib, w_sorted, (const float4*)pixel_grad_scratch, Ns, B, accumulate, (float4*)grad_spatial);
+        row_ptr, contrib, w_sorted, (const float4*)pixel_grad_scratch, Ns, accumulate, (float4*)grad_spatial);
     NF_LAUNCHED("gauss_row_reduce_kernel");
     return NERFAIL_OK;
 }

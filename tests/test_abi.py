@@ -40,6 +40,19 @@ def test_argument_validation_without_gpu():
     assert lib.nerfail_igsm_step(None, None, None, 10, 2.0, 32.0, 0, None, None) == 1
     with pytest.raises(_lib.NerfailError):
         _lib.check(lib.nerfail_gauss_weight(None, 1, 1, -1.0, None, None))
+    # sizing helpers are pure host functions
+    assert lib.nerfail_mlp_packed_T_floats(8, 256, 4) == 9 * 32 * 8 * 256 - 16 * 8 * 256    # 8 full layers + views (half the quads)
+    assert lib.nerfail_mlp_train_acts_floats(8, 256, 64) == 2 * (3 + 9 * 8 + 4) * 1024
+    assert lib.nerfail_mlp_train_dz_floats(8, 256, 33) == 2 * (8 * 8 + 8 + 4 + 1) * 1024
+    assert lib.nerfail_mlp_train_acts_floats(8, 100, 64) == 0
+    assert lib.nerfail_knn8_grid_workspace_bytes(7) == 0 and lib.nerfail_knn8_grid_workspace_bytes(1 << 24) == 0
+    assert lib.nerfail_knn8_grid_workspace_bytes(1920000) > 1920000 * 32
+    assert lib.nerfail_gauss_csr_workspace_bytes(1920000, 8, 640000) >= 3 * 4 * 8 * 640000 * 8
+    assert lib.nerfail_gauss_csr_workspace_bytes(10, 1 << 20, 1 << 20) == 0                 # ids would overflow 32 bits
+    assert lib.nerfail_knn8_grid(None, 4, None, 100, None, None, None, None, 0, None) == 1
+    assert lib.nerfail_composite_bwd(None, None, None, None, 3, 1, 1, None, None, None, None, None, None, None) == 1
+    assert lib.nerfail_mlp_bwd_data(None, None, 8, 100, 4, None, None, 10, None, None) == 1
+    assert b'unsupported' in lib.nerfail_last_error()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='CPU-only behaviour')
