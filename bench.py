@@ -214,6 +214,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-attack', action='store_true', help='skip the extra train / attack sections')
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on a 1-GPU box)')
+    ap.add_argument('--device', type=int, default=None, help='force the HIP device index (rehearsal: all ranks on GPU 0)')
     ap.add_argument('--sections', default='render,train,attack,knn',
                     help='comma list of render,train,attack,knn (profiling aid; the JSON line needs render)')
     args = ap.parse_args()
@@ -223,11 +225,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU path)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
 
     from nerfail_amd import nerf_to_coord as NC, run_nerf as RN
@@ -284,7 +290,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     assert torch.isfinite(out[0]).all()

@@ -1,0 +1,77 @@
+"""MI355X mirror of deepfool.py (reference root, `deepfool(...)` lines 10-111): the per-view inner loop of NeRFail
+(attack_NeRFail.py:396-402). Same signature and 5-tuple return (rot, loop_i, ori_cla_max_index, cla_max_index,
+spatial_rgb).
+
+The control flow (margins m1 / m2, per-class minimal step, accumulation, clamp, alpha restore) is host logic and
+stays Python, as SURVEY.md section 2 #10 scopes it; every forward / backward through the pixel<->3-D map runs in the
+HIP kernels behind `net` (gauss_net: K10 forward, K11 backward). One saving over the reference that cannot change the
+result: the gradient of the original class logit is computed once per iteration instead of once per competing class
+(the reference recomputes the identical tensor up to 7 times at deepfool.py:76-77).
+"""
+import torch
+
+
+def _grad(out_scalar, wrt):
+    return torch.autograd.grad(out_scalar, wrt, retain_graph=True, create_graph=False)[0]
+
+
+def deepfool(net_input, e, net, num_classes=8, max_iter=20, target_label: int = None, overshoot: float = 0.02,
+             m1: float = 1, m2: float = 30, universal_2d=False):
+    if universal_2d:
+        raise NotImplementedError('universal_2d is the 2-D baseline (attack_UAP_2D.py): out of scope, SURVEY.md section 2 #12')
+    spatial_rgb, weight_and_index, ori_img = net_input
+    spatial_rgb_0 = spatial_rgb.clone().detach()
+    spatial_rgb = spatial_rgb.detach().clone().requires_grad_(True)
+
+    _, _, cla, _, ori_cla = net(spatial_rgb, weight_and_index, ori_img)                 # deepfool.py:33
+    cla_max_index = torch.max(cla, 1)[1]
+    ori_cla_max_index = torch.max(ori_cla, 1)[1]
+    rot = torch.zeros_like(spatial_rgb_0)
+
+    loop_i = 0
+    while loop_i < max_iter:
+        spatial_rgb = spatial_rgb.detach().clone().requires_grad_(True)
+        _, _, cla, _, ori_cla = net(spatial_rgb, weight_and_index, ori_img)             # deepfool.py:51
+        ori_cla_max_index = torch.max(ori_cla, 1)[1]
+        o = int(ori_cla_max_index)
+        bump = torch.zeros_like(cla)                                                    # deepfool.py:53-57 (+m1), out of place
+        if target_label is None:
+            bump[:, o] = m1
+        else:
+            bump[:, :int(target_label)] = m1
+            bump[:, int(target_label) + 1:] = m1
+        cla = cla + bump
+        cla_max_index = torch.max(cla, 1)[1]
+        if (target_label is None) and int(cla_max_index) != o:
+            break
+        if (target_label is not None) and int(cla_max_index) == int(target_label):
+            break
+
+        grad_o = _grad(cla[:, o].sum(), spatial_rgb)
+        if target_label is None:
+            min_value = float('inf')
+            dr = torch.zeros_like(rot)
+            for k in range(num_classes):
+                if k == o:
+                    continue
+                grad_prime = _grad(cla[:, k].sum(), spatial_rgb) - grad_o
+                f_prime = (cla[:, k] - (cla[:, o] + m2)).detach()
+                nrm = torch.norm(grad_prime)
+                value_r = float(torch.abs(f_prime) / (nrm + 0.0001))
+                if value_r < min_value:
+                    dr = (torch.abs(f_prime) / ((nrm ** 2) + 0.0001)) * grad_prime
+                    min_value = value_r
+        else:
+            k = int(target_label)
+            grad_prime = _grad(cla[:, k].sum(), spatial_rgb) - grad_o
+            f_prime = (cla[:, k] - (cla[:, o] + m2)).detach()
+            dr = (torch.abs(f_prime) / ((torch.norm(grad_prime) ** 2) + 0.0001)) * grad_prime
+
+        rot = (rot + dr).detach()
+        spatial_rgb = torch.clamp((spatial_rgb_0 + (overshoot * rot)).detach(), -255, 255)
+        spatial_rgb = torch.cat([spatial_rgb[:, :, :, :3], spatial_rgb_0[:, :, :, 3].unsqueeze(-1)], -1)   # alpha unchanged
+        loop_i += 1
+
+    spatial_rgb = spatial_rgb.detach()
+    rot = (spatial_rgb - spatial_rgb_0).detach()
+    return rot, loop_i, ori_cla_max_index, cla_max_index, spatial_rgb

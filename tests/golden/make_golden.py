@@ -450,7 +450,35 @@ def g11():
     save('g11_igsm_step', **out)
 
 
+# ---------------------------------------------------------------- G12 deepfool (deepfool.py:10-111) through gauss_net
+def g12():
+    import deepfool as DF  # noqa: E402  (reference)
+    rs = np.random.RandomState(12)
+    P, H, W = 3, 32, 32
+    s = rs.uniform(-5, 5, size=(P, H, W, 4)).astype(np.float32)
+    s[..., 3] = 255.0
+    ori = synth.disc_alpha_image(1, H, W, seed=13)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(1, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, size=(1, H, W, 8)).astype(np.float32)
+    with torch.no_grad():
+        wi, _ = GN.create_gauss_w('cpu', 0.02)(T(np.stack([dist, idx], 1)))
+    out = dict(s=s, ori=ori, wi=wi.numpy(), cls_w=_PoolCls().w.detach().numpy() * 40.0)
+    for tag, target, over, iters in (('untargeted', None, 0.02, 6), ('targeted', 2, 0.02, 6), ('untargeted_break', None, 1.0, 12),
+                                     ('targeted_break', 2, 1.0, 12)):
+        cls = _PoolCls()
+        with torch.no_grad():
+            cls.w.mul_(40.0)                  # sharper logits so the margins (m1, m2) are reachable in a few steps
+        net = GN.gauss_net('cpu', 0.02, cls, 'my_model', epsilon=None)
+        rot, loop_i, ori_idx, cla_idx, s_new = DF.deepfool((T(s), wi, T(ori)), 1.0, net, num_classes=8, max_iter=iters,
+                                                           target_label=target, overshoot=over, m1=0.05, m2=0.5)
+        out.update({tag + '_rot': rot.detach().numpy(), tag + '_loop_i': loop_i, tag + '_ori_idx': int(ori_idx),
+                    tag + '_cla_idx': int(cla_idx), tag + '_s_new': s_new.detach().numpy()})
+        print(tag, 'loop_i', loop_i, 'ori', int(ori_idx), 'adv', int(cla_idx), '|rot|', float(rot.abs().max()))
+    save('g12_deepfool', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
     for w in which:
         globals()[w]()
+
