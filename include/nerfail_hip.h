@@ -122,6 +122,16 @@ int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, const float* pt
 int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int skip, const float* x, int64_t M,
                              float* raw, void* stream);
 
+/* ---- split-precision ("f16x3") forward: same contract as nerfail_mlp_fwd, fp32-equivalent results --------
+ * Every product a*w is evaluated as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the fp16 matrix cores with fp32
+ * accumulation (a_hi = fp16(a), a_lo = fp16(a - a_hi); weights pre-scaled by 2^10 inside the image). Opt-in: the
+ * default path is the exact-f32 kernel. `image`: nerfail_mlp_f16_image_bytes() bytes, filled by
+ * nerfail_mlp_pack_f16 from the nn.Linear tensors; `packed` is the f32 image of nerfail_mlp_pack (biases, heads). */
+size_t nerfail_mlp_f16_image_bytes(int D, int W, int skip);
+int nerfail_mlp_pack_f16(const nerfail_mlp_params* params_host, void* image, void* stream);
+int nerfail_mlp_fwd_f16(const float* packed, const void* image, int D, int W, int skip, const float* pts,
+                        const float* viewdirs, int64_t M, int samples_per_ray, float* raw, void* stream);
+
 /* ---- training step (RN:776-801): forward that saves activations, backward-data, weight gradients -------- */
 
 /* Floats of the activation / gradient scratch of one pass over M samples (0 = unsupported shape). */

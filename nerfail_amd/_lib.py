@@ -50,6 +50,9 @@ SIGNATURES = {
     'nerfail_mlp_pack': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
     'nerfail_mlp_fwd': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
     'nerfail_mlp_fwd_embedded': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p]),
+    'nerfail_mlp_f16_image_bytes': (ctypes.c_size_t, [c_i, c_i, c_i]),
+    'nerfail_mlp_pack_f16': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
+    'nerfail_mlp_fwd_f16': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
     'nerfail_mlp_train_acts_floats': (ctypes.c_size_t, [c_i, c_i, c_i64]),
     'nerfail_mlp_train_dz_floats': (ctypes.c_size_t, [c_i, c_i, c_i64]),
     'nerfail_mlp_fwd_train': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),

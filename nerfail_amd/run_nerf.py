@@ -41,6 +41,11 @@ def _mlp_points(fn, pts, viewdirs):
     """Fused encode + MLP on raw points: pts [R,N,3], viewdirs [R,3] -> raw [R,N,4] (nerfail_mlp_fwd)."""
     R, N = pts.shape[0], pts.shape[1]
     raw = torch.empty((R, N, 4), dtype=torch.float32, device=pts.device)
+    if getattr(fn, 'precision', 'f32') == 'f16x3':       # opt-in split-precision kernel (fp32-equivalent results)
+        _lib.check(_lib.load().nerfail_mlp_fwd_f16(_lib.dev(fn.packed()), _lib.dev(fn.packed_f16()), fn.D, fn.W, fn._skip(),
+                                                   _lib.dev(pts, 'pts'), _lib.dev(viewdirs, 'viewdirs'), R * N, N,
+                                                   _lib.dev(raw), _lib.stream()))
+        return raw
     _lib.check(_lib.load().nerfail_mlp_fwd(_lib.dev(fn.packed()), fn.D, fn.W, fn._skip(), _lib.dev(pts, 'pts'),
                                            _lib.dev(viewdirs, 'viewdirs'), R * N, N, _lib.dev(raw), _lib.stream()))
     return raw

@@ -77,6 +77,11 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(W, output_ch)
         self._packed = None
         self._packed_key = None
+        self._packed16 = None
+        self._packed16_key = None
+        # 'f32' : exact-f32 MFMA kernel (default).  'f16x3': split-precision fp16 MFMA kernel, fp32-equivalent
+        # results (each product as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi with fp32 accumulation), inference only.
+        self.precision = 'f32'
 
     # -- MFMA-fragment-ordered weight image, rebuilt when any parameter changes (data_ptr, _version)
     def _skip(self):
@@ -116,6 +121,40 @@ class NeRF(nn.Module):
         buf = torch.empty((n,), dtype=torch.float32, device=params[0].device)
         _lib.check(lib.nerfail_mlp_pack(mp, _lib.dev(buf), _lib.stream()))
         self._packed, self._packed_key = buf, key
+        return buf
+
+    def _mlp_params(self, keep):
+        mp = _lib.MlpParams()
+        mp.D, mp.W, mp.input_ch, mp.input_ch_views, mp.skip = self.D, self.W, self.input_ch, self.input_ch_views, self._skip()
+
+        def ptr(t):
+            t = _lib.f32c(t)
+            keep.append(t)
+            return t.data_ptr()
+        for i, l in enumerate(self.pts_linears):
+            mp.pts_w[i] = ptr(l.weight)
+            mp.pts_b[i] = ptr(l.bias)
+        mp.views_w, mp.views_b = ptr(self.views_linears[0].weight), ptr(self.views_linears[0].bias)
+        mp.feature_w, mp.feature_b = ptr(self.feature_linear.weight), ptr(self.feature_linear.bias)
+        mp.alpha_w, mp.alpha_b = ptr(self.alpha_linear.weight), ptr(self.alpha_linear.bias)
+        mp.rgb_w, mp.rgb_b = ptr(self.rgb_linear.weight), ptr(self.rgb_linear.bias)
+        return mp
+
+    def packed_f16(self):
+        """fp16 hi/lo weight image of the split-precision kernel (nerfail_mlp_pack_f16), cached like packed()."""
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed16 is not None and key == self._packed16_key:
+            return self._packed16
+        lib = _lib.load()
+        n = lib.nerfail_mlp_f16_image_bytes(self.D, self.W, self._skip())
+        if n == 0:
+            raise NotImplementedError('unsupported NeRF shape D=%d W=%d' % (self.D, self.W))
+        keep = []
+        mp = self._mlp_params(keep)
+        buf = torch.empty((n,), dtype=torch.uint8, device=params[0].device)
+        _lib.check(lib.nerfail_mlp_pack_f16(mp, _lib.dev(buf), _lib.stream()))
+        self._packed16, self._packed16_key = buf, key
         return buf
 
     def forward(self, x):

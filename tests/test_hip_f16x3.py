@@ -1,0 +1,80 @@
+"""-m gpu: the split-precision ("f16x3") MLP kernel against the SAME golden vectors and the SAME 1e-4 bound as the
+exact-f32 kernel, plus a direct error comparison of the two kernels against a float64 evaluation of the network."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from conftest import rel_err
+from hiputil import T, N, hip_nerf
+from oracle import nerf as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(net, pts, dirs):
+    from nerfail_amd.run_nerf import _mlp_points
+    return N(_mlp_points(net, T(pts), T(dirs)))
+
+
+@pytest.mark.parametrize('D,W', [(8, 256), (4, 64)])
+def test_f16x3_mlp_matches_reference(golden, D, W):
+    g = golden('g3_nerf_forward')
+    seed = int(g['seed_D%dW%d' % (D, W)])
+    _, net = hip_nerf(D, W, seed, precision='f16x3')
+    raw = _run(net, g['pts'].reshape(8, 64, 3), g['dirs'][:8])
+    if (D, W) == (8, 256):
+        assert rel_err(raw, g['run_network_raw']) < 1e-4
+    sd = synth.nerf_state_dict(D=D, W=W, seed=seed)
+    ref = O.run_network(sd, g['pts'].reshape(8, 64, 3), g['dirs'][:8], D=D, W=W)
+    assert rel_err(raw, ref) < 1e-4
+    # ragged sizes
+    for r, n in ((1, 64), (3, 21), (2, 33)):
+        got = _run(net, g['pts'][:r * n].reshape(r, n, 3), g['dirs'][:r])
+        assert rel_err(got, O.run_network(sd, g['pts'][:r * n].reshape(r, n, 3), g['dirs'][:r], D=D, W=W)) < 1e-4
+
+
+def test_f16x3_error_is_fp32_level():
+    """Both kernels vs the network evaluated in float64: the split-precision error must stay within a small factor
+    of the exact-f32 kernel's own rounding error (it is not a reduced-precision path)."""
+    rs = np.random.RandomState(0)
+    R, Ns = 64, 192
+    pts = rs.uniform(-2, 2, (R, Ns, 3)).astype(np.float32)
+    dirs = rs.normal(size=(R, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    sd, n32 = hip_nerf(8, 256, 5)
+    _, n16 = hip_nerf(8, 256, 5, precision='f16x3')
+    sd64 = {k: v.astype(np.float64) for k, v in sd.items()}
+    flat = pts.reshape(-1, 3)
+    d = np.broadcast_to(dirs[:, None, :], pts.shape).reshape(-1, 3)
+    emb = np.concatenate([O.embed(flat, 10), O.embed(d, 4)], -1).astype(np.float64)   # same float32 encoding values
+    ref = O.nerf_forward.__wrapped__(sd64, emb) if hasattr(O.nerf_forward, '__wrapped__') else None
+    # float64 forward (O.nerf_forward casts to float32, so restate the few lines here in float64)
+    h = emb[:, :63]
+    for i in range(8):
+        h = np.maximum(h @ sd64['pts_linears.%d.weight' % i].T + sd64['pts_linears.%d.bias' % i], 0)
+        if i == 4:
+            h = np.concatenate([emb[:, :63], h], -1)
+    alpha = h @ sd64['alpha_linear.weight'].T + sd64['alpha_linear.bias']
+    feat = h @ sd64['feature_linear.weight'].T + sd64['feature_linear.bias']
+    hv = np.maximum(np.concatenate([feat, emb[:, 63:]], -1) @ sd64['views_linears.0.weight'].T + sd64['views_linears.0.bias'], 0)
+    ref = np.concatenate([hv @ sd64['rgb_linear.weight'].T + sd64['rgb_linear.bias'], alpha], -1).reshape(R, Ns, 4)
+    e32 = np.abs(_run(n32, pts, dirs) - ref).max()
+    e16 = np.abs(_run(n16, pts, dirs) - ref).max()
+    scale = np.abs(ref).max()
+    assert e32 < 2e-5 * scale and e16 < 2e-5 * scale, (e32, e16, scale)
+    assert e16 < 8 * e32 + 1e-7 * scale, (e32, e16)
+
+
+def test_f16x3_render_matches_reference(golden):
+    from nerfail_amd import nerf_to_coord as NC
+    g = golden('g6_render_rays')
+    _, coarse = hip_nerf(8, 256, int(g['cfg2_seed_coarse']), precision='f16x3')
+    _, fine = hip_nerf(8, 256, int(g['cfg2_seed_fine']), precision='f16x3')
+    r = NC.render_rays(T(g['cfg2_rays']), coarse, None, 64, retraw=True, N_importance=128, network_fine=fine, white_bkgd=True)
+    for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'pts_max'):
+        assert rel_err(N(r[k]), g['cfg2_det_' + k]) < 1e-4, k
+    r = NC.render_rays(T(g['cfg2_rays']), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True,
+                       perturb=1., t_rand=T(g['cfg2_t_rand']), u=T(g['cfg2_u']))
+    for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'z_std', 'pts_max'):
+        assert rel_err(N(r[k]), g['cfg2_pert_' + k]) < 1e-4, k

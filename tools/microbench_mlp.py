@@ -40,7 +40,7 @@ def timeit(fn, reps=10):
 
 def main():
     m = net(1)
-    for R, N in ((1024, 64), (1024, 192), (8192, 192)):
+    for R, N in ((1024, 192), (8192, 192), (65536, 192)):
         M = R * N
         pts = torch.randn((R, N, 3), device=dev)
         vd = torch.nn.functional.normalize(torch.randn((R, 3), device=dev), dim=-1)
@@ -54,6 +54,12 @@ def main():
         def f_inf():
             _mlp_points(m, pts, vd)
 
+        m16 = net(1)
+        m16.precision = 'f16x3'
+
+        def f_f16():
+            _mlp_points(m16, pts, vd)
+
         def f_train():
             _train.mlp_fwd_train(m, pts, vd)
 
@@ -64,7 +70,7 @@ def main():
         def f_bw():
             _lib.check(lib.nerfail_mlp_bwd_weights(m.D, m.W, m._skip(), _lib.dev(acts), _lib.dev(dz), M,
                                                    _train._grads_struct(m, grads), _lib.stream()))
-        for name, fn in (('fwd_infer', f_inf), ('fwd_train', f_train), ('bwd_data', f_bd), ('bwd_weights', f_bw)):
+        for name, fn in (('fwd_infer', f_inf), ('fwd_f16x3', f_f16), ('fwd_train', f_train), ('bwd_data', f_bd), ('bwd_weights', f_bw)):
             med, mn = timeit(fn)
             print('M=%7d %-12s median %8.3f ms  min %8.3f ms  -> %6.1f TFLOP/s (fwd-equivalent FLOPs)' %
                   (M, name, med, mn, M * FLOP / (med * 1e-3) / 1e12), flush=True)
