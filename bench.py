@@ -118,6 +118,43 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024):
                          'note': 'whole step incl. sampling, compositing, Adam and host launch gaps; 3x forward FLOPs'}}
 
 
+def render_f16x3_bench(dev, steps=2):
+    """The same 800x800 render with the opt-in split-precision MLP kernel (NeRF.precision = 'f16x3': every product as
+    a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the fp16 matrix cores, fp32 accumulation; parity-tested at the same 1e-4 bound).
+    Reports rays/s and the max deviation of the rendered maps from the exact-f32 kernel on the same view."""
+    from nerfail_amd import nerf_to_coord as NC
+    nets = {}
+    for prec in ('f32', 'f16x3'):
+        _, c = make_net(21, dev)
+        _, f = make_net(22, dev)
+        c.precision = f.precision = prec
+        nets[prec] = (c, f)
+    focal, K = synth.lego_intrinsics(H, W)
+    c2w = torch.from_numpy(synth.pose_spherical(-117., -30., 4.)[:3, :4])
+
+    def run(prec):
+        c, f = nets[prec]
+        kw = dict(network_query_fn=None, perturb=0., N_importance=N_IMPORTANCE, network_fine=f, N_samples=N_SAMPLES,
+                  network_fn=c, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+        with torch.no_grad():
+            return NC.render(H, W, K, chunk=H * W, c2w=c2w, near=2., far=6., **kw)
+    ref = run('f32')
+    out = run('f16x3')
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(steps):
+        out = run('f16x3')
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / steps
+    dev_rgb = float((out[0] - ref[0]).abs().max())
+    dev_acc = float((out[2] - ref[2]).abs().max())
+    samples = H * W * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)
+    return {'rays_per_sec': H * W / dt, 'ms_per_view': dt * 1e3, 'speedup_vs_f32_kernel_this_run': None,
+            'fp32_equivalent_tflops_whole_step': samples * FLOP_PER_SAMPLE / dt / 1e12,
+            'max_abs_dev_rgb_vs_f32_kernel': dev_rgb, 'max_abs_dev_acc_vs_f32_kernel': dev_acc,
+            'note': 'opt-in mode; the headline value above is the exact-f32 kernel'}
+
+
 def knn_bench(dev, reps=2):
     """8-NN index build of ONE view (create_index_and_dist.py:126-145): 640 000 queries (the view's pts_max) against the
     1 920 000-point set of 3 base views; synthetic shell points. Exact (d2, index) ordering."""
@@ -216,8 +253,8 @@ def main():
     ap.add_argument('--no-attack', action='store_true', help='skip the extra train / attack sections')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL; default) or gloo (rehearsal on a 1-GPU box)')
     ap.add_argument('--device', type=int, default=None, help='force the HIP device index (rehearsal: all ranks on GPU 0)')
-    ap.add_argument('--sections', default='render,train,attack,knn',
-                    help='comma list of render,train,attack,knn (profiling aid; the JSON line needs render)')
+    ap.add_argument('--sections', default='render,train,attack,knn,f16x3',
+                    help='comma list of render,train,attack,knn,f16x3 (profiling aid; the JSON line needs render)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -246,6 +283,8 @@ def main():
             out['attack'] = attack_bench(dev)
         if 'knn' in sections:
             out['knn'] = knn_bench(dev)
+        if 'f16x3' in sections:
+            out['render_f16x3'] = render_f16x3_bench(dev)
         print(json.dumps(out), flush=True)
         return
 
@@ -336,6 +375,9 @@ def main():
                 line['attack'] = attack_bench(dev)
             if 'knn' in sections:
                 line['knn'] = knn_bench(dev)
+            if 'f16x3' in sections:
+                line['render_f16x3'] = render_f16x3_bench(dev)
+                line['render_f16x3']['speedup_vs_f32_kernel_this_run'] = line['render_f16x3']['rays_per_sec'] / line['value']
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -71,6 +71,29 @@ __device__ __forceinline__ double wave_scan_add_f64(double v, int lane) {
 // -fhip-fp32-correctly-rounded-divide-sqrt, like the `/` behind __fdiv_rn.
 __device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
 
+// sin / cos of x * 2^f for the positional-encoding bands f = 0 .. L-1 (run_nerf_helpers.py:36-41).
+// The product x * 2^f is exact in float32, so the reference evaluates sin / cos of exactly that real number (with a
+// ~1 ulp libm). All bands share one argument reduction: u0 = x * (2/pi) in double (relative error 2^-53), band f is
+// u = u0 * 2^f (exact), q = rint(u), w = u - q in [-0.5, 0.5] quadrants, phi = w * pi/2 in [-pi/4, pi/4], then the
+// classic single-precision minimax polynomials (Cephes sinf / cosf kernels, < 1 ulp on that interval) and a quadrant
+// rotation. ~25 instructions per (sin, cos) pair instead of a full-range sincosf with Payne-Hanek fallback per call.
+struct SinCosBands {
+    double u0;
+    __device__ __forceinline__ explicit SinCosBands(float x) : u0((double)x * 0.63661977236758134308) {}
+    __device__ __forceinline__ void band(int f, float& sn, float& cs) const {
+        const double u = u0 * (double)(1 << f);
+        const double q = __builtin_rint(u);
+        const float phi = (float)(u - q) * 1.57079632679489661923f;
+        const float z = phi * phi;
+        const float s = phi + phi * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+        const float c = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+        const int k = (int)q & 3;                 // two's complement & 3 == q mod 4 also for negative q
+        const float ss = (k & 1) ? c : s, cc = (k & 1) ? s : c;
+        sn = (k & 2) ? -ss : ss;
+        cs = ((k + 1) & 2) ? -cc : cc;
+    }
+};
+
 // pts = o + d*z with the reference's rounding (multiply, then add; no FMA): RN:381
 __device__ __forceinline__ float mul_add_rn(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }
 

@@ -16,12 +16,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
         return;
     }
-    const float f = (float)(1 << (band - 1));    // freq_bands = 2**linspace(0, L-1, L): exact powers of two
+    // freq_bands = 2**linspace(0, L-1, L): exact powers of two; same evaluation as the fused kernels (SinCosBands)
     float* ob = o + 3 + 6 * (band - 1);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         float sn, cs;
-        sincosf(__fmul_rn(v[d], f), &sn, &cs);
+        SinCosBands(v[d]).band(band - 1, sn, cs);
         ob[d] = sn;
         ob[3 + d] = cs;
     }

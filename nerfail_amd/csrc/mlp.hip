@@ -17,7 +17,8 @@
 //     lane order, so each weight read is one fully coalesced 16-byte-per-lane load covering 4 MFMA
 //     k-steps. The 2.4 MB image stays L2-resident; all waves stream it in the same order.
 //   * Positional encoding is computed per lane in registers: MFMA step s of the encoding part needs,
-//     for lane half 0 / 1, sin / cos of the SAME argument x_d*2^f, i.e. one sincosf per step.
+//     for lane half 0 / 1, sin / cos of the SAME argument x_d*2^f: one (sin, cos) pair per step, and all bands of
+//     a coordinate share ONE double-precision argument reduction (SinCosBands, common.h).
 //   * alpha_linear (W->1) and rgb_linear (W/2->3) are too thin for a 32-wide MFMA tile: VALU dot
 //     products on the accumulator registers + one cross-half shuffle.
 // Bound: f32 MFMA (157 TFLOP/s dense on MI355X); algorithmic work 1 186 816 FLOP per sample (D8 W256).
@@ -117,23 +118,27 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
             const float* vd = a.viewdirs + 3 * (s / a.spr);
             const float vx[3] = {vd[0], vd[1], vd[2]};
 #pragma unroll
-            for (int f = 0; f < 10; ++f)
+            for (int d = 0; d < 3; ++d) {
+                const SinCosBands sc(px[d]);           // sin / cos of x * 2^f for all bands, one shared reduction
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
+                for (int f = 0; f < 10; ++f) {
                     float sn, cs;
-                    sincosf(__fmul_rn(px[d], (float)(1 << f)), &sn, &cs);   // x * 2^f exactly as RH:39-41
+                    sc.band(f, sn, cs);
                     emb[3 * f + d] = h ? cs : sn;
                 }
+            }
             emb[30] = h ? px[1] : px[0];
             emb[31] = h ? 0.f : px[2];
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int d = 0; d < 3; ++d) {
+                const SinCosBands sc(vx[d]);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
+                for (int f = 0; f < 4; ++f) {
                     float sn, cs;
-                    sincosf(__fmul_rn(vx[d], (float)(1 << f)), &sn, &cs);
+                    sc.band(f, sn, cs);
                     demb[3 * f + d] = h ? cs : sn;
                 }
+            }
             demb[12] = h ? vx[1] : vx[0];
             demb[13] = h ? 0.f : vx[2];
             demb[14] = 0.f; demb[15] = 0.f;

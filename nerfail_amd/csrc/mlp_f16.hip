@@ -14,9 +14,16 @@
 // packed, are the 8-element fp16 fragment of k16-step s (hi) and its residual (lo). 128 packed operand registers
 // + 128 accumulators per wave.
 // Weights: the A operand must be re-streamed for every 32 samples, 32 B per lane per 3 MFMAs (96 cycles): 4 waves
-// would ask the L1 for 85 B/clk/CU. So a workgroup streams the image ONCE into an LDS ring (coalesced 16-byte
-// loads, register-staged, two k16-steps ahead) and the 4 waves read their fragments from LDS (ds_read_b128,
-// conflict-free lane-linear layout); one barrier per k16-step (24 MFMAs per wave).
+// would ask the L1 for 85 B/clk/CU. So the WORKGROUP streams the image once through LDS and its 4 waves read their
+// fragments from there (ds_read_b128, lane-linear = conflict-free). The image is one continuous sequence of
+// fixed-size chunks (NT*2 KB = one k16-step x NT out tiles, or two steps x NT/2 tiles for the views layer) in
+// consumption order over the WHOLE network; the stream never stops at a layer or tile boundary:
+//     step c, phase A:  ds_read 2nd half of chunk c | ds_write chunk c+1 | global loads of chunk c+3
+//                       MFMAs on the 1st half of chunk c (fragments read during the previous step)     -> barrier
+//             phase B:  ds_read 1st half of chunk c+1 (now visible) | MFMAs on the 2nd half of chunk c
+// so every LDS read has 12 MFMAs (~400 cycles) of cover and the LDS writes / global loads ride under the MFMAs.
+// 2-slot LDS ring, 2 register stages; every part has an even chunk count (views padded), so ring slot and stage
+// index are compile-time constants.
 #include "mlp_layout.h"
 
 namespace nerfail {
@@ -28,30 +35,32 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr float kWScale = 1024.0f, kWInv = 1.0f / 1024.0f;
 constexpr int kEmbK16 = 4, kDirK16 = 2;      // 64 / 32 padded encoding channels
 
-// fp16 image: per MFMA layer, per k16-step ks, per out tile t: hi fragment then lo fragment, each [64 lanes][8 halfs]
-// (1 KB). Offsets in units of 16 bytes (one lane fragment).
+// fp16 image: a sequence of chunks of NT*2*64 fragments (16 B each). A chunk = [step-in-chunk][tile][hi|lo][lane],
+// steps per chunk = 1 for the NT-tile layers and 2 for the NT/2-tile views layer. Per layer the chunk count is padded
+// to an even number (zero chunks that are streamed but not computed).
 struct F16Layout {
     int NT, D, skip;
-    unsigned off[NERFAIL_MAX_DEPTH + 2];      // [0..D-1] pts, [D] feature, [D+1] views; units: 16 B
-    unsigned nk16[NERFAIL_MAX_DEPTH + 2];     // k16-steps of the layer
-    unsigned total;                           // 16-byte units
+    unsigned chunk0[NERFAIL_MAX_DEPTH + 2];   // first chunk of layer l ([0..D-1] pts, [D] feature, [D+1] views)
+    unsigned nchunks[NERFAIL_MAX_DEPTH + 2];  // padded chunk count of layer l
+    unsigned total_chunks;
 };
 
 static bool make_f16_layout(int D, int W, int skip, F16Layout& L) {
     MlpLayout M;
     if (!make_layout(D, W, skip, M)) return false;
     L.NT = M.NT; L.D = D; L.skip = M.skip;
-    unsigned off = 0;
+    unsigned c = 0;
     for (int l = 0; l <= D + 1; ++l) {
-        const int OT = (l == D + 1) ? M.NT / 2 : M.NT;
         int k16 = 0;
         if (l <= D - 1 && layer_has_emb(l, M.skip)) k16 += kEmbK16;
         if (l > 0) k16 += 2 * M.NT;
         if (l == D + 1) k16 += kDirK16;
-        L.off[l] = off; L.nk16[l] = (unsigned)k16;
-        off += (unsigned)k16 * OT * 2 * 64;
+        int n = (l == D + 1) ? (k16 + 1) / 2 : k16;
+        n = (n + 1) & ~1;
+        L.chunk0[l] = c; L.nchunks[l] = (unsigned)n;
+        c += (unsigned)n;
     }
-    L.total = off;
+    L.total_chunks = c;
     return true;
 }
 
@@ -73,14 +82,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 }
 
 // ------------------------------------------------------------------------------------- packing
-// one thread per (k16, tile, lane, element j): writes hi and lo halfs of W[row][col] * 2^10
+// one thread per (k16-step, tile, lane, element j) of ONE layer: writes hi and lo halfs of W[row][col] * 2^10.
+// spc = steps per chunk (1: OT == NT, 2: OT == NT/2); chunk bytes = NT*2 KB either way.
 __global__ void pack_f16_layer_kernel(const float* __restrict__ w, int out_f, int in_f, int OT, int NT, int emb_col0,
                                       int h_col0, int dir_col0, _Float16* __restrict__ img, int total) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const int j = g & 7, lane = (g >> 3) & 63, rest = g >> 9;
     const int t = rest % OT;
-    int ks = rest / OT;
+    const int step = rest / OT;
+    int ks = step;
     const int hh = lane >> 5, row = 32 * t + (lane & 31);
     int col = -1;
     if (emb_col0 >= 0) {
@@ -97,8 +108,11 @@ __global__ void pack_f16_layer_kernel(const float* __restrict__ w, int out_f, in
     const float v = (row < out_f && col >= 0) ? w[(long)row * in_f + col] * kWScale : 0.f;
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
-    // g enumerates [ks][t][lane][j]; the image is [ks][t][hi|lo][lane][j]
-    const long base = ((long)(g >> 9) * 2) * 512 + (lane * 8 + j);
+    // image position: chunk = step / spc; inside the chunk [step % spc][t][hi|lo][lane][j]
+    const int spc = NT / OT;
+    const long chunk = step / spc;
+    const long in_chunk = ((long)(step % spc) * OT + t) * 2;
+    const long base = (chunk * NT * 2 + in_chunk) * 512 + (lane * 8 + j);    // halfs
     img[base] = hi;
     img[base + 512] = lo;
 }
@@ -116,8 +130,6 @@ struct F16Args {
     F16Layout l16;
 };
 
-constexpr int kRing = 2;        // LDS ring depth in k16-steps: chunk ks+2 is only written after every wave passed barrier ks+1
-
 template <int OT>
 __device__ __forceinline__ void load_bias_scaled(f32x16 (&acc)[OT], const float* __restrict__ b, int h) {
 #pragma unroll
@@ -129,48 +141,81 @@ __device__ __forceinline__ void load_bias_scaled(f32x16 (&acc)[OT], const float*
     }
 }
 
-// One part of a layer: NK k16-steps. The workgroup streams chunk (k16-step) after chunk of the image through the LDS
-// ring; bsel(ks, hi, lo) yields this wave's B fragments of step ks.
-//   ring[(slot)][t][hi|lo][lane] as u32x4; chunk = OT*2*64 u32x4 = OT KB * 2
-template <int OT, int NK, typename BSel>
-__device__ __forceinline__ void f16_part(f32x16 (&acc)[OT], const u32x4* __restrict__ img, u32x4* __restrict__ ring,
-                                         int tid, int lane, BSel bsel) {
-    constexpr int CH = OT * 2 * 64;               // u32x4 per chunk
-    constexpr int PER_T = (CH + 255) / 256;       // u32x4 each thread moves per chunk (OT*128/256 = OT/2)
-    const bool mover = (CH % 256 == 0) || tid < CH;   // W = 64: the 1-tile views chunk is 128 fragments
-    u32x4 stage[2][PER_T];                        // register staging: two chunks in flight
-    // prologue: chunks 0 and 1 -> registers; chunk 0 -> LDS
+// The weight stream of one workgroup. CH = fragments per chunk, PER_T = fragments each thread moves per chunk.
+// A chunk holds NT (hi, lo) fragment pairs: pair p = [step-in-chunk][tile]; "first half" = pairs 0..NT/2-1.
+template <int NT>
+struct WStream {
+    static constexpr int CH = NT * 2 * 64;
+    static constexpr int PER_T = CH / 256;
+    static constexpr int HP = NT / 2;      // fragment pairs per half chunk
+    const u32x4* gp;          // this lane's global read position: chunk (c+3) when step c starts
+    const u32x4* img;         // image start (lane-adjusted)
+    unsigned left;            // chunks until the image wraps
+    unsigned total;
+    u32x4 st[2][PER_T];       // register stages: st[x] holds the chunk with parity x that is next to be written
+    u32x4 fa[HP][2];          // first-half fragments of the CURRENT chunk (prefetched during the previous step)
+};
+
+template <int NT>
+__device__ __forceinline__ void stream_load(WStream<NT>& w, u32x4 (&dst)[WStream<NT>::PER_T]) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-        if (c < NK) {
+    for (int i = 0; i < WStream<NT>::PER_T; ++i) dst[i] = w.gp[i * 256];
+    w.gp += WStream<NT>::CH;
+    if (--w.left == 0) { w.gp = w.img; w.left = w.total; }       // next tile starts over (workgroup-uniform)
+}
+
+template <int NT>
+__device__ __forceinline__ void read_half(u32x4 (&dst)[NT / 2][2], const u32x4* __restrict__ rp, int slot, int half) {
 #pragma unroll
-            for (int i = 0; i < PER_T; ++i) stage[c][i] = img[(long)c * CH + (mover ? i * 256 + tid : 0)];
-        }
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-        u32x4* slot = ring + (ks % kRing) * CH;
-        // chunk ks: registers -> LDS (its global loads were issued two steps ago), then refill the stage with ks + 2
-#pragma unroll
-        for (int i = 0; i < PER_T; ++i)
-            if (mover) slot[i * 256 + tid] = stage[ks & 1][i];
-        if (ks + 2 < NK) {
-#pragma unroll
-            for (int i = 0; i < PER_T; ++i) stage[ks & 1][i] = img[(long)(ks + 2) * CH + (mover ? i * 256 + tid : 0)];
-        }
-        __syncthreads();                          // chunk ks visible to all 4 waves; the other slot is free for ks + 1
-        u32x4 bhi, blo;
-        bsel(ks, bhi, blo);
-        const h8 bh = __builtin_bit_cast(h8, bhi), bl = __builtin_bit_cast(h8, blo);
-#pragma unroll
-        for (int t = 0; t < OT; ++t) {
-            const h8 ah = __builtin_bit_cast(h8, slot[(t * 2 + 0) * 64 + lane]);
-            const h8 al = __builtin_bit_cast(h8, slot[(t * 2 + 1) * 64 + lane]);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-        }
+    for (int p = 0; p < NT / 2; ++p) {
+        dst[p][0] = rp[slot * WStream<NT>::CH + ((half * (NT / 2) + p) * 2 + 0) * 64];
+        dst[p][1] = rp[slot * WStream<NT>::CH + ((half * (NT / 2) + p) * 2 + 1) * 64];
     }
-    __syncthreads();                              // everyone is done with the ring before the next part refills it
+}
+
+// One part of a layer: NCH chunks (even), each holding SPC k16-steps for OT = NT/SPC out tiles; the last PADC chunks
+// are zero padding (streamed, not computed). Entry invariant = exit invariant: chunk 0 of the part is visible in LDS
+// slot 0, its first-half fragments are in w.fa, st[1] holds chunk 1, st[0] holds chunk 2 (loads in flight).
+template <int NT, int SPC, int NCH, int PADC, typename BSel>
+__device__ __forceinline__ void f16_part(f32x16 (&acc)[NT / SPC], WStream<NT>& w, u32x4* __restrict__ ring, int tid, int lane,
+                                         BSel bsel) {
+    constexpr int OT = NT / SPC, CH = WStream<NT>::CH, PER_T = WStream<NT>::PER_T, HP = NT / 2;
+    static_assert(NCH % 2 == 0, "parts must have an even chunk count");
+    static_assert(SPC == 1 || SPC == 2, "one or two k16-steps per chunk");
+    u32x4* __restrict__ wp = ring + tid;            // lane pointers: every LDS / global access is pointer + constant
+    const u32x4* __restrict__ rp = ring + lane;
+    // pair p of a chunk -> (step-in-chunk, tile): SPC == 1: (0, p); SPC == 2: (p / OT, p % OT) with OT == HP
+    auto mfma_half = [&](int c, int half, const u32x4 (&fr)[HP][2]) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)                 // x-outer: 3 independent rounds over the tiles (hh, hl, lh)
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+                const int pair = half * HP + p;
+                const int sp = (SPC == 1) ? 0 : pair / OT, t = (SPC == 1) ? pair : pair % OT;
+                u32x4 bhi, blo;
+                bsel(c * SPC + sp, bhi, blo);
+                const h8 ah = __builtin_bit_cast(h8, fr[p][0]), al = __builtin_bit_cast(h8, fr[p][1]);
+                const h8 bh = __builtin_bit_cast(h8, bhi), bl = __builtin_bit_cast(h8, blo);
+                if (x == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                else if (x == 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+            }
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool live = c < NCH - PADC;
+        // ---- phase A
+        u32x4 fb[HP][2];
+        read_half<NT>(fb, rp, c & 1, 1);            // second half of chunk c
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) wp[((c + 1) & 1) * CH + i * 256] = w.st[(c + 1) & 1][i];   // chunk c+1 -> LDS
+        stream_load<NT>(w, w.st[(c + 1) & 1]);      // chunk c+3 -> the stage just freed
+        if (live) mfma_half(c, 0, w.fa);
+        __syncthreads();                            // chunk c+1 visible; nobody reads slot (c+1)&1's old content any more
+        // ---- phase B
+        read_half<NT>(w.fa, rp, (c + 1) & 1, 0);    // first half of chunk c+1 (possibly the next part's chunk 0)
+        if (live) mfma_half(c, 1, fb);
+    }
 }
 
 template <int NT>
@@ -179,6 +224,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* ring = reinterpret_cast<u32x4*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int kViewsSteps = 2 * NT + kDirK16;                     // k16-steps of the views layer
+    constexpr int kViewsChunks = (((kViewsSteps + 1) / 2) + 1) & ~1;  // 2 steps per chunk, padded to even
+    constexpr int kViewsPad = kViewsChunks - (kViewsSteps + 1) / 2;
+    static_assert(kViewsSteps % 2 == 0, "views k16-steps fill whole chunks");
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const float* __restrict__ P = a.packed;
@@ -186,6 +235,17 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
     const F16Layout& L16 = a.l16;
     const long ntiles = (a.M + 31) / 32;
     const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);
+
+    // ---- start the weight stream: chunk 0 -> LDS slot 0, chunks 1 and 2 -> register stages
+    WStream<NT> ws;
+    ws.img = a.img + tid; ws.gp = ws.img; ws.total = L16.total_chunks; ws.left = ws.total;
+    stream_load<NT>(ws, ws.st[0]);
+#pragma unroll
+    for (int i = 0; i < WStream<NT>::PER_T; ++i) ring[tid + i * 256] = ws.st[0][i];
+    stream_load<NT>(ws, ws.st[1]);
+    stream_load<NT>(ws, ws.st[0]);
+    __syncthreads();
+    read_half<NT>(ws.fa, ring + lane, 0, 0);
 
     for (long rnd = 0; rnd < nrounds; ++rnd) {
         // every wave of the workgroup runs every round (barriers inside): out-of-range tiles compute on a clamped
@@ -200,23 +260,27 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
             const float* vd = a.viewdirs + 3 * (s / a.spr);
             const float vx[3] = {vd[0], vd[1], vd[2]};
 #pragma unroll
-            for (int f = 0; f < 10; ++f)
+            for (int d = 0; d < 3; ++d) {
+                const SinCosBands sc(px[d]);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
+                for (int f = 0; f < 10; ++f) {
                     float sn, cs;
-                    sincosf(__fmul_rn(px[d], (float)(1 << f)), &sn, &cs);
+                    sc.band(f, sn, cs);
                     emb[3 * f + d] = h ? cs : sn;
                 }
+            }
             emb[30] = h ? px[1] : px[0];
             emb[31] = h ? 0.f : px[2];
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
+            for (int d = 0; d < 3; ++d) {
+                const SinCosBands sc(vx[d]);
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
+                for (int f = 0; f < 4; ++f) {
                     float sn, cs;
-                    sincosf(__fmul_rn(vx[d], (float)(1 << f)), &sn, &cs);
+                    sc.band(f, sn, cs);
                     demb[3 * f + d] = h ? cs : sn;
                 }
+            }
             demb[12] = h ? vx[1] : vx[0];
             demb[13] = h ? 0.f : vx[2];
             demb[14] = 0.f; demb[15] = 0.f;
@@ -257,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
 
         // ---- layer 0
         load_bias_scaled<NT>(acc, P + L.b_off[0], h);
-        f16_part<NT, kEmbK16>(acc, a.img + L16.off[0], ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = ehi[ks]; lo = elo[ks]; });
+        f16_part<NT, 1, kEmbK16, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = ehi[ks]; lo = elo[ks]; });
         to_operands(true);
 
         float alpha = 0.f;
@@ -282,23 +346,19 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
                 alpha = sacc + wa[NT * 32];
             }
             load_bias_scaled<NT>(acc, P + L.b_off[l], h);
-            const u32x4* img = a.img + L16.off[l];
-            if (l == L.skip + 1 && L.skip >= 0) {
-                f16_part<NT, kEmbK16>(acc, img, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = ehi[ks]; lo = elo[ks]; });
-                img += kEmbK16 * NT * 2 * 64;
-            }
-            f16_part<NT, 2 * NT>(acc, img, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
+            if (l == L.skip + 1 && L.skip >= 0)
+                f16_part<NT, 1, kEmbK16, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = ehi[ks]; lo = elo[ks]; });
+            f16_part<NT, 1, 2 * NT, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
             to_operands(l < L.D);
         }
 
         // ---- views_linears[0]
         f32x16 hv[OTV];
         load_bias_scaled<OTV>(hv, P + L.b_off[L.D + 1], h);
-        {
-            const u32x4* img = a.img + L16.off[L.D + 1];
-            f16_part<OTV, 2 * NT>(hv, img, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
-            f16_part<OTV, kDirK16>(hv, img + 2 * NT * OTV * 2 * 64, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = dhi[ks]; lo = dlo[ks]; });
-        }
+        f16_part<NT, 2, kViewsChunks, kViewsPad>(hv, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) {
+            if (ks < 2 * NT) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; }
+            else { hi = dhi[ks - 2 * NT]; lo = dlo[ks - 2 * NT]; }
+        });
         // ---- rgb_linear on VALU (fp32)
         const float* wr = P + L.rgb_off;
         float rgb[3];
@@ -323,7 +383,7 @@ using namespace nerfail;
 
 extern "C" size_t nerfail_mlp_f16_image_bytes(int D, int W, int skip) {
     F16Layout L;
-    return make_f16_layout(D, W, skip, L) ? (size_t)L.total * 16 : 0;
+    return make_f16_layout(D, W, skip, L) ? (size_t)L.total_chunks * L.NT * 2 * 64 * 16 : 0;
 }
 
 extern "C" int nerfail_mlp_pack_f16(const nerfail_mlp_params* p, void* image, void* stream) {
@@ -333,6 +393,10 @@ extern "C" int nerfail_mlp_pack_f16(const nerfail_mlp_params* p, void* image, vo
     NF_REQUIRE(make_f16_layout(p->D, p->W, p->skip, L), "unsupported (D, W)");
     hipStream_t s = as_stream(stream);
     const int W = p->W, NT = L.NT, OTV = NT / 2;
+    {   // padding chunks must be zero (they are streamed, never multiplied, but keep the image deterministic)
+        hipError_t e = hipMemsetAsync(image, 0, (size_t)L.total_chunks * NT * 2 * 64 * 16, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    }
     for (int l = 0; l <= p->D + 1; ++l) {
         const bool emb = l <= p->D - 1 && layer_has_emb(l, L.skip);
         const float* w;
@@ -350,9 +414,14 @@ extern "C" int nerfail_mlp_pack_f16(const nerfail_mlp_params* p, void* image, vo
             NF_REQUIRE(p->views_w != nullptr, "views_linears pointer is NULL");
             w = p->views_w; out_f = W / 2; in_f = W + kDirCh; OT = OTV; h0 = 0; dir0 = W;
         }
-        const int total = (int)L.nk16[l] * OT * 512;     // one thread per (k16, tile, lane, j)
+        int k16 = 0;
+        if (emb0 >= 0) k16 += kEmbK16;
+        if (h0 >= 0) k16 += 2 * NT;
+        if (dir0 >= 0) k16 += kDirK16;
+        const int total = k16 * OT * 512;                // one thread per (k16-step, tile, lane, j)
         pack_f16_layer_kernel<<<dim3((total + 255) / 256), dim3(256), 0, s>>>(
-            w, out_f, in_f, OT, NT, emb0, h0, dir0, reinterpret_cast<_Float16*>(image) + (size_t)L.off[l] * 8, total);
+            w, out_f, in_f, OT, NT, emb0, h0, dir0,
+            reinterpret_cast<_Float16*>(image) + (size_t)L.chunk0[l] * NT * 2 * 512, total);
         NF_LAUNCHED("pack_f16_layer_kernel");
     }
     return NERFAIL_OK;
@@ -378,7 +447,7 @@ extern "C" int nerfail_mlp_fwd_f16(const float* packed, const void* image, int D
     if (blocks > cus) blocks = cus;
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = as_stream(stream);
-    const size_t lds = (size_t)kRing * a.lay.NT * 2 * 64 * 16;      // ring of kRing chunks of NT*2 KB
+    const size_t lds = (size_t)2 * a.lay.NT * 2 * 64 * 16;          // 2-slot ring of NT*2 KB chunks
     switch (W) {
         case 256: nerf_mlp_fwd_f16_kernel<8><<<grid, block, lds, s>>>(a); break;
         case 128: nerf_mlp_fwd_f16_kernel<4><<<grid, block, lds, s>>>(a); break;
