@@ -364,10 +364,6 @@ def main():
                          'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
                          'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline()
-        else:
-            line['cpu_baseline'] = None
         if not args.no_attack and world == 1:
             if 'train' in sections:
                 line['train'] = train_bench(dev)
@@ -378,6 +374,9 @@ def main():
             if 'f16x3' in sections:
                 line['render_f16x3'] = render_f16x3_bench(dev)
                 line['render_f16x3']['speedup_vs_f32_kernel_this_run'] = line['render_f16x3']['rays_per_sec'] / line['value']
+        # the CPU baseline runs LAST: its 256 OpenBLAS worker threads keep spinning for a while after the last sgemm and
+        # starve the Python launch thread of whatever GPU section follows (seen as a 7x slower training section)
+        line['cpu_baseline'] = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
