@@ -71,13 +71,14 @@ def cpu_baseline(seconds_budget=20.0):
                       '(oracle/nerf.py, OpenBLAS sgemm on all host cores), %.1f s' % (n, dt)}
 
 
-def train_bench(dev, steps=10, warmup=2, n_rand=1024):
+def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     """NeRF training step (RN:776-801) at the shipped config (configs/lego.txt: N_rand=1024, 64+128 samples,
     D=8 W=256, perturb=1, white_bkgd): render -> mse(rgb)+mse(rgb0) -> backward -> Adam. rays/s (fwd+bwd)."""
     from nerfail_amd import run_nerf as RN
     from nerfail_amd.run_nerf import ray_gen
     _, coarse = make_net(31, dev)
     _, fine = make_net(32, dev)
+    coarse.precision = fine.precision = precision
     params = list(coarse.parameters()) + list(fine.parameters())
     for p in params:
         p.requires_grad_(True)
@@ -111,7 +112,7 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024):
     torch.cuda.synchronize()
     dt = (time.time() - t) / steps
     flop = n_rand * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE) * FLOP_PER_SAMPLE * 3     # fwd + bwd-data + bwd-weights
-    return {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand,
+    return {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand, 'precision': precision,
             'final_loss': float(loss.detach()),
             'roofline': {'bound': 'mfma', 'achieved': flop / dt / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': flop / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
@@ -284,6 +285,7 @@ def main():
         if 'knn' in sections:
             out['knn'] = knn_bench(dev)
         if 'f16x3' in sections:
+            out['train_f16x3'] = train_bench(dev, precision='f16x3')
             out['render_f16x3'] = render_f16x3_bench(dev)
         print(json.dumps(out), flush=True)
         return
@@ -372,6 +374,7 @@ def main():
             if 'knn' in sections:
                 line['knn'] = knn_bench(dev)
             if 'f16x3' in sections:
+                line['train_f16x3'] = train_bench(dev, precision='f16x3')
                 line['render_f16x3'] = render_f16x3_bench(dev)
                 line['render_f16x3']['speedup_vs_f32_kernel_this_run'] = line['render_f16x3']['rays_per_sec'] / line['value']
         # the CPU baseline runs LAST: its 256 OpenBLAS worker threads keep spinning for a while after the last sgemm and

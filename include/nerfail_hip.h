@@ -131,6 +131,17 @@ size_t nerfail_mlp_f16_image_bytes(int D, int W, int skip);
 int nerfail_mlp_pack_f16(const nerfail_mlp_params* params_host, void* image, void* stream);
 int nerfail_mlp_fwd_f16(const float* packed, const void* image, int D, int W, int skip, const float* pts,
                         const float* viewdirs, int64_t M, int samples_per_ray, float* raw, void* stream);
+/* Same, additionally saving the fp32 activation tiles exactly like nerfail_mlp_fwd_train (the backward kernels
+ * consume them unchanged). */
+int nerfail_mlp_fwd_f16_train(const float* packed, const void* image, int D, int W, int skip, const float* pts,
+                              const float* viewdirs, int64_t M, int samples_per_ray, float* raw, float* acts,
+                              void* stream);
+
+/* Split-precision backward-data: same contract as nerfail_mlp_bwd_data with the transposed fp16 image. */
+size_t nerfail_mlp_f16_image_T_bytes(int D, int W, int skip);
+int nerfail_mlp_pack_f16_T(const nerfail_mlp_params* params_host, void* imageT, void* stream);
+int nerfail_mlp_bwd_data_f16(const float* packed, const void* imageT, int D, int W, int skip, const float* d_raw,
+                             const float* acts, int64_t M, float* dz, void* stream);
 
 /* ---- training step (RN:776-801): forward that saves activations, backward-data, weight gradients -------- */
 
@@ -150,6 +161,11 @@ int nerfail_mlp_bwd_data(const float* packed, const float* packedT, int D, int W
  * weights); every gradient is ACCUMULATED into (+=, float atomics), so zero them for a fresh gradient. */
 int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
                             const nerfail_mlp_params* grads_host, void* stream);
+
+/* Same with the operands converted in registers to bf16 hi/lo pairs and 3 bf16 MFMAs per product block (fp32
+ * accumulation, fp32 exponent range, ~1.5e-5 relative per product: a gradient-grade opt-in mode). */
+int nerfail_mlp_bwd_weights_bf16x3(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
+                                   const nerfail_mlp_params* grads_host, void* stream);
 
 /* ------------------------------------------------------------------ compositing (K5, K7) -- */
 

@@ -53,6 +53,10 @@ SIGNATURES = {
     'nerfail_mlp_f16_image_bytes': (ctypes.c_size_t, [c_i, c_i, c_i]),
     'nerfail_mlp_pack_f16': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
     'nerfail_mlp_fwd_f16': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
+    'nerfail_mlp_fwd_f16_train': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
+    'nerfail_mlp_f16_image_T_bytes': (ctypes.c_size_t, [c_i, c_i, c_i]),
+    'nerfail_mlp_pack_f16_T': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
+    'nerfail_mlp_bwd_data_f16': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
     'nerfail_mlp_train_acts_floats': (ctypes.c_size_t, [c_i, c_i, c_i64]),
     'nerfail_mlp_train_dz_floats': (ctypes.c_size_t, [c_i, c_i, c_i64]),
     'nerfail_mlp_fwd_train': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
@@ -60,6 +64,7 @@ SIGNATURES = {
     'nerfail_mlp_pack_T': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
     'nerfail_mlp_bwd_data': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
     'nerfail_mlp_bwd_weights': (c_i, [c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.POINTER(MlpParams), c_p]),
+    'nerfail_mlp_bwd_weights_bf16x3': (c_i, [c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.POINTER(MlpParams), c_p]),
     'nerfail_composite': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_composite_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_knn8': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),

@@ -52,11 +52,32 @@ def packed_T(net):
     return buf
 
 
+def packed_f16_T(net):
+    """fp16 hi/lo image of the transposed weights (split-precision backward-data), cached on parameter versions."""
+    params = ordered_params(net)
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    if getattr(net, '_packed16T', None) is not None and net._packed16T_key == key:
+        return net._packed16T
+    lib = _lib.load()
+    n = lib.nerfail_mlp_f16_image_T_bytes(net.D, net.W, net._skip())
+    keep = [_lib.f32c(p) for p in params]
+    mp = _grads_struct(net, keep)
+    buf = torch.empty((n,), dtype=torch.uint8, device=params[0].device)
+    _lib.check(lib.nerfail_mlp_pack_f16_T(mp, _lib.dev(buf), _lib.stream()))
+    net._packed16T, net._packed16T_key = buf, key
+    return buf
+
+
 def mlp_fwd_train(net, pts, viewdirs):
     lib = _lib.load()
     R, N = pts.shape[0], pts.shape[1]
     raw = torch.empty((R, N, 4), dtype=torch.float32, device=pts.device)
     acts = torch.empty((lib.nerfail_mlp_train_acts_floats(net.D, net.W, R * N),), dtype=torch.float32, device=pts.device)
+    if getattr(net, 'precision', 'f32') == 'f16x3':        # split-precision forward, same saved activations
+        _lib.check(lib.nerfail_mlp_fwd_f16_train(_lib.dev(net.packed()), _lib.dev(net.packed_f16()), net.D, net.W, net._skip(),
+                                                 _lib.dev(pts), _lib.dev(viewdirs), R * N, N, _lib.dev(raw), _lib.dev(acts),
+                                                 _lib.stream()))
+        return raw, acts
     _lib.check(lib.nerfail_mlp_fwd_train(_lib.dev(net.packed()), net.D, net.W, net._skip(), _lib.dev(pts), _lib.dev(viewdirs),
                                          R * N, N, _lib.dev(raw), _lib.dev(acts), _lib.stream()))
     return raw, acts
@@ -67,10 +88,14 @@ def mlp_backward(net, d_raw, acts, grads):
     lib = _lib.load()
     M = d_raw.shape[0] * d_raw.shape[1]
     dz = torch.empty((lib.nerfail_mlp_train_dz_floats(net.D, net.W, M),), dtype=torch.float32, device=d_raw.device)
-    _lib.check(lib.nerfail_mlp_bwd_data(_lib.dev(net.packed()), _lib.dev(packed_T(net)), net.D, net.W, net._skip(),
-                                        _lib.dev(d_raw), _lib.dev(acts), M, _lib.dev(dz), _lib.stream()))
-    _lib.check(lib.nerfail_mlp_bwd_weights(net.D, net.W, net._skip(), _lib.dev(acts), _lib.dev(dz), M,
-                                           _grads_struct(net, grads), _lib.stream()))
+    if getattr(net, 'precision', 'f32') == 'f16x3':
+        _lib.check(lib.nerfail_mlp_bwd_data_f16(_lib.dev(net.packed()), _lib.dev(packed_f16_T(net)), net.D, net.W, net._skip(),
+                                                _lib.dev(d_raw), _lib.dev(acts), M, _lib.dev(dz), _lib.stream()))
+    else:
+        _lib.check(lib.nerfail_mlp_bwd_data(_lib.dev(net.packed()), _lib.dev(packed_T(net)), net.D, net.W, net._skip(),
+                                            _lib.dev(d_raw), _lib.dev(acts), M, _lib.dev(dz), _lib.stream()))
+    fn = lib.nerfail_mlp_bwd_weights_bf16x3 if getattr(net, 'precision', 'f32') == 'f16x3' else lib.nerfail_mlp_bwd_weights
+    _lib.check(fn(net.D, net.W, net._skip(), _lib.dev(acts), _lib.dev(dz), M, _grads_struct(net, grads), _lib.stream()))
 
 
 def composite_backward(raw, z_vals, rays, noise, white_bkgd, g_rgb, g_disp, g_acc, g_depth=None, g_weights=None):
@@ -84,6 +109,16 @@ def composite_backward(raw, z_vals, rays, noise, white_bkgd, g_rgb, g_disp, g_ac
                                                  int(bool(white_bkgd)), _lib.dev(g_rgb), _lib.dev(g_disp), _lib.dev(g_acc),
                                                  _lib.dev(g_depth), _lib.dev(g_weights), _lib.dev(d_raw), _lib.stream()))
     return d_raw
+
+
+def _zero_grads(net):
+    ps = ordered_params(net)
+    flat = torch.zeros((sum(p.numel() for p in ps),), dtype=torch.float32, device=ps[0].device)
+    out, off = [], 0
+    for p in ps:
+        out.append(flat[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    return out
 
 
 class RenderRaysTrain(torch.autograd.Function):
@@ -103,7 +138,7 @@ class RenderRaysTrain(torch.autograd.Function):
         cfg, sv = ctx.cfg, ctx.saved
         coarse, fine = cfg['network_fn'], cfg['network_fine']
         nets = [coarse] + ([fine] if fine is not None else [])
-        grads = {id(n): [torch.zeros_like(p, dtype=torch.float32) for p in ordered_params(n)] for n in nets}
+        grads = {id(n): _zero_grads(n) for n in nets}      # one memset per network, sliced into per-parameter views
         wb = cfg['white_bkgd']
         if sv['fine'] is not None:
             f = sv['fine']

@@ -57,6 +57,45 @@ __global__ void pack_layer_kernel(const float* __restrict__ w, const float* __re
     wq[g] = (row < out_f && col >= 0) ? w[(long)row * in_f + col] : 0.f;
 }
 
+// All MFMA layers in ONE launch (the image is re-packed after every optimizer step): a table of per-layer
+// descriptors passed by value; a block works on one layer (blockIdx.y), grid-striding over its elements.
+struct PackLayerDesc {
+    const float* w; const float* b;
+    int out_f, in_f, OT, emb0, h0, dir0, total_w;
+    unsigned w_off, b_off;
+};
+struct PackTable { int n, NT; PackLayerDesc l[NERFAIL_MAX_DEPTH + 2]; };
+
+__global__ void pack_all_layers_kernel(PackTable t, float* __restrict__ packed) {
+    const PackLayerDesc& d = t.l[blockIdx.y];
+    const int n = d.total_w > d.OT * 32 ? d.total_w : d.OT * 32;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+        if (g < d.OT * 32) {
+            const int tt = g / 32, hh = (g / 16) & 1, r = g & 15;
+            const int ch = 32 * tt + acc_channel(r, hh);
+            packed[d.b_off + g] = (ch < d.out_f) ? d.b[ch] : 0.f;
+        }
+        if (g >= d.total_w) continue;
+        const int e = g & 3, lane = (g >> 2) & 63, rest = g >> 8;
+        const int tt = rest % d.OT;
+        int q = rest / d.OT;
+        const int hh = lane >> 5, row = 32 * tt + (lane & 31);
+        int col = -1;
+        if (d.emb0 >= 0) {
+            if (q < kEmbQuads) { const int c = enc_channel(4 * q + e, hh, 10); col = c < 0 ? -1 : d.emb0 + c; q = -1; }
+            else q -= kEmbQuads;
+        }
+        if (q >= 0 && d.h0 >= 0) {
+            if (q < t.NT * 4) { const int s_ = 4 * q + e; col = d.h0 + 32 * (s_ / 16) + acc_channel(s_ % 16, hh); q = -1; }
+            else q -= t.NT * 4;
+        }
+        if (q >= 0 && d.dir0 >= 0) {
+            const int c = enc_channel(4 * q + e, hh, 4); col = c < 0 ? -1 : d.dir0 + c;
+        }
+        packed[d.w_off + g] = (row < d.out_f && col >= 0) ? d.w[(long)row * d.in_f + col] : 0.f;
+    }
+}
+
 // alpha image [NT][2][16] + bias, rgb image [3][OTV][2][16] + 3 biases
 __global__ void pack_heads_kernel(const float* __restrict__ aw, const float* __restrict__ ab,
                                   const float* __restrict__ rw, const float* __restrict__ rb, int W,
@@ -289,26 +328,27 @@ extern "C" int nerfail_mlp_pack(const nerfail_mlp_params* p, float* packed, void
                "head pointer is NULL");
     hipStream_t s = as_stream(stream);
     const int W = p->W, NT = L.NT, OTV = NT / 2;
+    PackTable tab;
+    tab.n = p->D + 2; tab.NT = NT;
     for (int l = 0; l <= p->D + 1; ++l) {
         const bool emb = l <= p->D - 1 && layer_has_emb(l, L.skip);
-        const float *w, *b;
-        int out_f, in_f, OT = NT, emb0 = -1, h0 = -1, dir0 = -1;
+        PackLayerDesc& d = tab.l[l];
+        d.OT = NT; d.emb0 = -1; d.h0 = -1; d.dir0 = -1;
         if (l < p->D) {
-            w = p->pts_w[l]; b = p->pts_b[l]; out_f = W;
-            in_f = (l == 0) ? kPtsCh : (emb ? W + kPtsCh : W);
-            if (emb) emb0 = 0;
-            if (l > 0) h0 = emb ? kPtsCh : 0;
+            d.w = p->pts_w[l]; d.b = p->pts_b[l]; d.out_f = W;
+            d.in_f = (l == 0) ? kPtsCh : (emb ? W + kPtsCh : W);
+            if (emb) d.emb0 = 0;
+            if (l > 0) d.h0 = emb ? kPtsCh : 0;
         } else if (l == p->D) {
-            w = p->feature_w; b = p->feature_b; out_f = W; in_f = W; h0 = 0;
+            d.w = p->feature_w; d.b = p->feature_b; d.out_f = W; d.in_f = W; d.h0 = 0;
         } else {
-            w = p->views_w; b = p->views_b; out_f = W / 2; in_f = W + kDirCh; OT = OTV; h0 = 0; dir0 = W;
+            d.w = p->views_w; d.b = p->views_b; d.out_f = W / 2; d.in_f = W + kDirCh; d.OT = OTV; d.h0 = 0; d.dir0 = W;
         }
-        const int total_w = (int)(L.b_off[l] - L.w_off[l]);
-        const int n = total_w > OT * 32 ? total_w : OT * 32;
-        pack_layer_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(w, b, out_f, in_f, OT, NT, emb0, h0, dir0,
-                                                                      packed + L.w_off[l], packed + L.b_off[l], total_w);
-        NF_LAUNCHED("pack_layer_kernel");
+        d.total_w = (int)(L.b_off[l] - L.w_off[l]);
+        d.w_off = L.w_off[l]; d.b_off = L.b_off[l];
     }
+    pack_all_layers_kernel<<<dim3(64, (unsigned)tab.n), dim3(256), 0, s>>>(tab, packed);
+    NF_LAUNCHED("pack_all_layers_kernel");
     const int nh = (NT * 32 + 4) > (3 * OTV * 32 + 4) ? (NT * 32 + 4) : (3 * OTV * 32 + 4);
     pack_heads_kernel<<<dim3((nh + 255) / 256), dim3(256), 0, s>>>(p->alpha_w, p->alpha_b, p->rgb_w, p->rgb_b, W,
                                                                   packed + L.alpha_off, packed + L.rgb_off);

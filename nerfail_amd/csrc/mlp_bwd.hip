@@ -157,6 +157,7 @@ struct WArgs {
     long ntiles;               // 32-sample tiles
     int a_slots, z_slots;
     int ndesc, ntasks, ngroups;            // a group = 4 consecutive tasks = the 4 waves of a workgroup
+    int bf16x3;                            // 0: exact f32 MFMA, 1: bf16 hi/lo split (dw_task_bf16)
     int group_cost[kMaxTasks / 4 + 1];     // MFMAs per k-step of the group's heaviest task
     long cum[kMaxTasks / 4 + 2];           // prefix sums of group_cost * ntiles (work units)
     LinDesc desc[kMaxDesc];
@@ -264,6 +265,129 @@ __device__ __forceinline__ void dw_task(const WArgs& a, const WTask tk, int lane
     }
 }
 
+// ---- split-precision form of the same task (opt-in, WArgs::bf16x3): the operands are converted IN REGISTERS to bf16
+// hi / lo pairs (a = a_hi + a_lo, 16 significant bits, fp32's exponent range - so no scaling is needed for gradients of
+// any magnitude) and every product block is ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16: 3 MFMAs of 32 cycles
+// per 16 samples instead of 8 f32 MFMAs of 64 cycles. ~1.5e-5 relative per product, far inside what a stochastic
+// gradient needs (and the 5e-3 parity bound). k16-step mapping: (step ks, half kh, element j) <-> sample 16*ks + 8*kh + j,
+// i.e. each lane reads 8 contiguous floats (two 16-byte loads) per operand and step.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16(const f32x4& v0, const f32x4& v1, u32x4b& hi, u32x4b& lo) {
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    unsigned hb[8], lb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hb[i] = __float_as_uint(v[i]) & 0xffff0000u;                      // bf16(a), truncated
+        lb[i] = __float_as_uint(v[i] - __uint_as_float(hb[i]));           // exact residual, truncated to bf16 below
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                                         // element 2p in the low half, 2p+1 in the high half
+        hi[p] = (hb[2 * p] >> 16) | hb[2 * p + 1];
+        lo[p] = (lb[2 * p] >> 16) | (lb[2 * p + 1] & 0xffff0000u);
+    }
+}
+
+template <int MA, int NB>
+__device__ __forceinline__ void dw_task_bf16(const WArgs& a, const WTask tk, int lane, long t_begin, long t_end) {
+    const LinDesc& d = a.desc[tk.desc];
+    const XPart& xp = d.parts[tk.part];
+    const int c = lane & 31, kh = lane >> 5;
+    int offA[MA], offB[NB];
+#pragma unroll
+    for (int m = 0; m < MA; ++m) offA[m] = (d.dz_slot0 + 4 * tk.ob + m) * 1024 + c * 32 + 8 * kh;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) offB[n] = (xp.slot0 + 4 * tk.ib + n) * 1024 + c * 32 + 8 * kh;
+    f32x16 acc[MA][NB];
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    float rowsum[MA];
+#pragma unroll
+    for (int m = 0; m < MA; ++m) rowsum[m] = 0.f;
+    const bool do_bias = (d.gb != nullptr) && tk.part == 0 && tk.ib == 0;
+    if (t_begin >= t_end) return;
+    const float* __restrict__ zb = a.dz + (size_t)t_begin * a.z_slots * 1024;
+    const float* __restrict__ xb = a.acts + (size_t)t_begin * a.a_slots * 1024;
+    f32x4 ra[MA][2], rb[NB][2], na[MA][2], nb[NB][2];       // raw fp32 operands of the current / next k16-step
+#pragma unroll
+    for (int m = 0; m < MA; ++m) { ra[m][0] = *reinterpret_cast<const f32x4*>(zb + offA[m]); ra[m][1] = *reinterpret_cast<const f32x4*>(zb + offA[m] + 4); }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) { rb[n][0] = *reinterpret_cast<const f32x4*>(xb + offB[n]); rb[n][1] = *reinterpret_cast<const f32x4*>(xb + offB[n] + 4); }
+    for (long ts = t_begin; ts < t_end; ++ts) {
+        const bool last_tile = ts + 1 >= t_end;
+        const float* __restrict__ zn = last_tile ? zb : zb + (size_t)a.z_slots * 1024;
+        const float* __restrict__ xn = last_tile ? xb : xb + (size_t)a.a_slots * 1024;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // prefetch the next k16-step (step 1 of this tile, or step 0 of the next tile)
+#pragma unroll
+            for (int m = 0; m < MA; ++m) {
+                const float* src = (ks == 0) ? zb + offA[m] + 16 : zn + offA[m];
+                na[m][0] = *reinterpret_cast<const f32x4*>(src); na[m][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const float* src = (ks == 0) ? xb + offB[n] + 16 : xn + offB[n];
+                nb[n][0] = *reinterpret_cast<const f32x4*>(src); nb[n][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4b ah[MA], al[MA], bh[NB], bl[NB];
+#pragma unroll
+            for (int m = 0; m < MA; ++m) {
+                split_bf16(ra[m][0], ra[m][1], ah[m], al[m]);
+                if (do_bias) rowsum[m] += (ra[m][0][0] + ra[m][0][1]) + (ra[m][0][2] + ra[m][0][3]) + (ra[m][1][0] + ra[m][1][1]) + (ra[m][1][2] + ra[m][1][3]);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) split_bf16(rb[n][0], rb[n][1], bh[n], bl[n]);
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int m = 0; m < MA; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        const bf8 A_ = __builtin_bit_cast(bf8, x == 2 ? al[m] : ah[m]);
+                        const bf8 B_ = __builtin_bit_cast(bf8, x == 1 ? bl[n] : bh[n]);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[m][n], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MA; ++m) { ra[m][0] = na[m][0]; ra[m][1] = na[m][1]; }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) { rb[n][0] = nb[n][0]; rb[n][1] = nb[n][1]; }
+        }
+        zb = zn;
+        xb = xn;
+    }
+#pragma unroll
+    for (int m = 0; m < MA; ++m) {
+        const int tt = 4 * tk.ob + m;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int col = 32 * (4 * tk.ib + n) + c;
+            if (col >= xp.ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * tt + acc_channel(r, kh);
+                if (row >= d.row0 && row < d.row1)
+                    atomicAdd(d.gw + (long)(row - d.row0) * d.in_f + xp.col0 + col, acc[m][n][r]);
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+            const float sres = rowsum[m] + __shfl_xor(rowsum[m], 32, 64);
+            const int row = 32 * (4 * tk.ob + m) + c;
+            if (kh == 0 && row >= d.row0 && row < d.row1) atomicAdd(d.gb + (row - d.row0), sres);
+        }
+    }
+}
+
 // Persistent grid (one workgroup per CU: 256 accumulator registers per lane leave room for one wave per SIMD).
 // The work "group g over sample tile t" costs group_cost[g] MFMAs per k-step; the flattened (group-major) sequence of
 // all such items is cut into gridDim.x equal-cost intervals, so every workgroup computes the same number of MFMAs
@@ -290,6 +414,19 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_kernel(WArgs a) {
         ma = ma > 4 ? 4 : ma;
         nb = nb > 4 ? 4 : nb;
         // wave-uniform dispatch on the block shape (the shapes a NeRF produces; anything else takes the padded path)
+        if (a.bf16x3) {
+            if (ma == 4 && nb == 4) dw_task_bf16<4, 4>(a, tk, lane, t_begin, t_end);
+            else if (ma == 4 && nb == 2) dw_task_bf16<4, 2>(a, tk, lane, t_begin, t_end);
+            else if (ma == 4 && nb == 1) dw_task_bf16<4, 1>(a, tk, lane, t_begin, t_end);
+            else if (ma == 1 && nb == 4) dw_task_bf16<1, 4>(a, tk, lane, t_begin, t_end);
+            else if (ma == 2 && nb == 2) dw_task_bf16<2, 2>(a, tk, lane, t_begin, t_end);
+            else if (ma == 2 && nb == 1) dw_task_bf16<2, 1>(a, tk, lane, t_begin, t_end);
+            else if (ma == 1 && nb == 2) dw_task_bf16<1, 2>(a, tk, lane, t_begin, t_end);
+            else if (ma == 1 && nb == 1) dw_task_bf16<1, 1>(a, tk, lane, t_begin, t_end);
+            else if (ma == 2 && nb == 4) dw_task_bf16<2, 4>(a, tk, lane, t_begin, t_end);
+            else dw_task_bf16<4, 4>(a, tk, lane, t_begin, t_end);
+            continue;
+        }
         if (ma == 4 && nb == 4) dw_task<4, 4>(a, tk, lane, t_begin, t_end);
         else if (ma == 4 && nb == 2) dw_task<4, 2>(a, tk, lane, t_begin, t_end);
         else if (ma == 4 && nb == 1) dw_task<4, 1>(a, tk, lane, t_begin, t_end);
@@ -386,8 +523,21 @@ extern "C" int nerfail_mlp_bwd_data(const float* packed, const float* packedT, i
     return NERFAIL_OK;
 }
 
+static int bwd_weights_impl(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
+                            const nerfail_mlp_params* grads_host, int bf16x3, void* stream);
+
 extern "C" int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
                                        const nerfail_mlp_params* grads_host, void* stream) {
+    return bwd_weights_impl(D, W, skip, acts, dz, M, grads_host, 0, stream);
+}
+
+extern "C" int nerfail_mlp_bwd_weights_bf16x3(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
+                                              const nerfail_mlp_params* grads_host, void* stream) {
+    return bwd_weights_impl(D, W, skip, acts, dz, M, grads_host, 1, stream);
+}
+
+static int bwd_weights_impl(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
+                            const nerfail_mlp_params* grads_host, int bf16x3, void* stream) {
     NF_REQUIRE(M >= 0, "M is negative");
     MlpLayout L;
     NF_REQUIRE(make_layout(D, W, skip, L), "unsupported (D, W)");
@@ -398,7 +548,7 @@ extern "C" int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts
     const TrainLayout TL = make_train_layout(D, W);
     const int NT = L.NT, OTV = NT / 2;
     WArgs a;
-    a.acts = acts; a.dz = dz; a.ntiles = (M + 31) / 32; a.a_slots = TL.a_slots; a.z_slots = TL.z_slots;
+    a.acts = acts; a.dz = dz; a.ntiles = (M + 31) / 32; a.a_slots = TL.a_slots; a.z_slots = TL.z_slots; a.bf16x3 = bf16x3;
     int nd = 0;
     auto add = [&](int dz_slot0, int dz_tiles, int row0, int row1, int in_f, float* gw, float* gb) -> LinDesc& {
         LinDesc& d = a.desc[nd++];

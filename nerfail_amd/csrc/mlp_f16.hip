@@ -117,6 +117,44 @@ __global__ void pack_f16_layer_kernel(const float* __restrict__ w, int out_f, in
     img[base + 512] = lo;
 }
 
+// the whole image in ONE launch: per-layer descriptors by value, a block row (blockIdx.y) per layer
+struct PackF16Desc { const float* w; int out_f, in_f, OT, emb0, h0, dir0, total; unsigned long dst_halfs; };
+struct PackF16Table { int n, NT; PackF16Desc l[NERFAIL_MAX_DEPTH + 2]; };
+
+__global__ void pack_f16_all_kernel(PackF16Table t, _Float16* __restrict__ image) {
+    const PackF16Desc& d = t.l[blockIdx.y];
+    _Float16* __restrict__ img = image + d.dst_halfs;
+    const int NT = t.NT, OT = d.OT;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < d.total; g += gridDim.x * blockDim.x) {
+        const int j = g & 7, lane = (g >> 3) & 63, rest = g >> 9;
+        const int tt = rest % OT;
+        const int step = rest / OT;
+        int ks = step;
+        const int hh = lane >> 5, row = 32 * tt + (lane & 31);
+        int col = -1;
+        if (d.emb0 >= 0) {
+            if (ks < kEmbK16) { const int c = enc_channel(8 * ks + j, hh, 10); col = c < 0 ? -1 : d.emb0 + c; ks = -1; }
+            else ks -= kEmbK16;
+        }
+        if (ks >= 0 && d.h0 >= 0) {
+            if (ks < 2 * NT) { col = d.h0 + 32 * (ks >> 1) + acc_channel(8 * (ks & 1) + j, hh); ks = -1; }
+            else ks -= 2 * NT;
+        }
+        if (ks >= 0 && d.dir0 >= 0) {
+            const int c = enc_channel(8 * ks + j, hh, 4); col = c < 0 ? -1 : d.dir0 + c;
+        }
+        const float v = (row < d.out_f && col >= 0) ? d.w[(long)row * d.in_f + col] * kWScale : 0.f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int spc = NT / OT;
+        const long chunk = step / spc;
+        const long in_chunk = ((long)(step % spc) * OT + tt) * 2;
+        const long base = (chunk * NT * 2 + in_chunk) * 512 + (lane * 8 + j);
+        img[base] = hi;
+        img[base + 512] = lo;
+    }
+}
+
 // ------------------------------------------------------------------------------------- forward kernel
 struct F16Args {
     const float* packed;        // fp32 image of mlp.hip: biases and the alpha / rgb head weights
@@ -124,6 +162,7 @@ struct F16Args {
     const float* pts;
     const float* viewdirs;
     float* raw;
+    float* acts;                // training: channel-major activation tiles, same layout as nerfail_mlp_fwd_train
     long M;
     int spr;
     MlpLayout lay;
@@ -218,7 +257,7 @@ __device__ __forceinline__ void f16_part(f32x16 (&acc)[NT / SPC], WStream<NT>& w
     }
 }
 
-template <int NT>
+template <int NT, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
     constexpr int OTV = NT / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -304,7 +343,17 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
 
         f32x16 acc[NT];
         u32x4 bh[NT][2], bl[NT][2];           // packed operands of the current layer input (hi / lo per k16-step)
-        auto to_operands = [&](bool relu) {   // acc (scaled by 2^10) -> next layer's B fragments
+        const bool save = TRAIN && tile < ntiles;                    // wave-uniform
+        float* __restrict__ A = nullptr;                             // this tile's activation slots (training)
+        float* __restrict__ lpA = nullptr;                           // lane pointer for accumulator-layout stores
+        if (TRAIN && save) {
+            A = a.acts + (size_t)tile * ((3 + (L.D + 1) * NT + NT / 2) * 1024);
+            lpA = A + (lane >> 5) * 128 + (lane & 31);
+            store_enc<10, 32>(A, emb, lane);
+            store_enc<4, 16>(A + 2 * 1024, demb, lane);
+        }
+        // acc (scaled by 2^10) -> next layer's B fragments; training also saves the fp32 activation (slot0 = first slot)
+        auto to_operands = [&](bool relu, int slot0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -314,6 +363,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
                     for (int q = 0; q < 8; ++q) {
                         const float x = acc[t][8 * sgrp + q] * kWInv;
                         v[q] = relu ? fmaxf(x, 0.f) : x;
+                        if (TRAIN && save) {
+                            const int r = 8 * sgrp + q;
+                            lpA[(slot0 + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = v[q];
+                        }
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
                 }
@@ -322,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
         // ---- layer 0
         load_bias_scaled<NT>(acc, P + L.b_off[0], h);
         f16_part<NT, 1, kEmbK16, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = ehi[ks]; lo = elo[ks]; });
-        to_operands(true);
+        to_operands(true, 3);
 
         float alpha = 0.f;
 #pragma unroll 1
@@ -349,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
             if (l == L.skip + 1 && L.skip >= 0)
                 f16_part<NT, 1, kEmbK16, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = ehi[ks]; lo = elo[ks]; });
             f16_part<NT, 1, 2 * NT, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
-            to_operands(l < L.D);
+            to_operands(l < L.D, 3 + l * NT);      // H_{l+1} for l < D, F for l == D
         }
 
         // ---- views_linears[0]
@@ -359,6 +412,13 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
             if (ks < 2 * NT) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; }
             else { hi = dhi[ks - 2 * NT]; lo = dlo[ks - 2 * NT]; }
         });
+        if (TRAIN && save) {
+#pragma unroll
+            for (int t = 0; t < OTV; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    lpA[(3 + (L.D + 1) * NT + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = fmaxf(hv[t][r] * kWInv, 0.f);
+        }
         // ---- rgb_linear on VALU (fp32)
         const float* wr = P + L.rgb_off;
         float rgb[3];
@@ -374,6 +434,173 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
         }
         if (h == 0 && sraw < a.M)
             reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);
+    }
+}
+
+// ------------------------------------------------------------------------------------- backward data (f16x3)
+// dX = W^T dZ with the same split-precision scheme and the same LDS weight stream. The W^T image is a chunk sequence
+// in BACKWARD order: views^T (K = W/2), feature^T, pts_{D-1}^T .. pts_1^T (K = W each), all NT in-tiles wide.
+// Gradients are tiny (d_raw ~ 1e-5), so each wave scales its d_raw by an exact power of two S (max |d_raw| -> [1,2));
+// every dZ is stored divided by S again, i.e. unscaled and bit-comparable with the f32 kernel's layout.
+struct F16LayoutT {
+    unsigned chunk0[NERFAIL_MAX_DEPTH + 2];   // index: 0 = views^T, 1 = feature^T, 2 + k = pts_{D-1-k}^T (k = 0 .. D-2)
+    unsigned total_chunks;
+};
+static void make_f16_layout_T(int D, int NT, F16LayoutT& L) {
+    unsigned c = 0;
+    L.chunk0[0] = c; c += 2 * (NT / 2);
+    for (int k = 1; k <= D; ++k) { L.chunk0[k] = c; c += 2 * NT; }
+    L.total_chunks = c;
+}
+
+// one thread per (k16-step, in-tile, lane, j): A[row = input channel 32t + lane&31][k = out channel of slot (ks, hh, j)]
+__global__ void pack_f16_layer_T_kernel(const float* __restrict__ w, int out_f, int in_f, int col0, int NT,
+                                        _Float16* __restrict__ img, int total) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int j = g & 7, lane = (g >> 3) & 63, rest = g >> 9;
+    const int t = rest % NT, ks = rest / NT;
+    const int hh = lane >> 5;
+    const int o = 32 * (ks >> 1) + acc_channel(8 * (ks & 1) + j, hh);
+    const int i = 32 * t + (lane & 31);
+    const float v = (o < out_f) ? w[(long)o * in_f + col0 + i] * kWScale : 0.f;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const long base = ((long)ks * NT * 2 + (long)t * 2) * 512 + (lane * 8 + j);
+    img[base] = hi;
+    img[base + 512] = lo;
+}
+
+struct F16BwdArgs {
+    const float* packed;        // fp32 image (alpha / rgb head weights)
+    const u32x4* imgT;          // fp16 hi/lo image of the transposed weights
+    const float* d_raw;
+    const float* acts;
+    float* dz;
+    long M;
+    unsigned total_chunks;
+    MlpLayout lay;
+    TrainLayout tl;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArgs a) {
+    constexpr int OTV = NT / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* ring = reinterpret_cast<u32x4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const float* __restrict__ P = a.packed;
+    const MlpLayout& L = a.lay;
+    const TrainLayout& TL = a.tl;
+    const long ntiles = (a.M + 31) / 32;
+    const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);
+
+    WStream<NT> ws;
+    ws.img = a.imgT + tid; ws.gp = ws.img; ws.total = a.total_chunks; ws.left = ws.total;
+    stream_load<NT>(ws, ws.st[0]);
+#pragma unroll
+    for (int i = 0; i < WStream<NT>::PER_T; ++i) ring[tid + i * 256] = ws.st[0][i];
+    stream_load<NT>(ws, ws.st[1]);
+    stream_load<NT>(ws, ws.st[0]);
+    __syncthreads();
+    read_half<NT>(ws.fa, ring + lane, 0, 0);
+
+    for (long rnd = 0; rnd < nrounds; ++rnd) {
+        const long tile = (rnd * gridDim.x + blockIdx.x) * 4 + wave;
+        const bool live = tile < ntiles;                                   // wave-uniform; dead waves still run the barriers
+        const long tl_ = live ? tile : ntiles - 1;
+        const long sraw = tl_ * 32 + j;
+        const float* __restrict__ A = a.acts + (size_t)tl_ * TL.a_slots * 1024;
+        float* __restrict__ Z = a.dz + (size_t)tl_ * TL.z_slots * 1024;
+        float* __restrict__ lpZ = Z + (lane >> 5) * 128 + (lane & 31);
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && sraw < a.M) dr = reinterpret_cast<const float4*>(a.d_raw)[sraw];
+        // exact power-of-two scale of this wave's gradients: max |d_raw| -> [1, 2)
+        float smax = wave_max(fmaxf(fmaxf(fabsf(dr.x), fabsf(dr.y)), fmaxf(fabsf(dr.z), fabsf(dr.w))));
+        int ex = 0;
+        if (smax > 0.f) (void)frexpf(smax, &ex);                           // smax = m * 2^ex, m in [0.5, 1)
+        const float S = ldexpf(1.0f, 1 - ex), Sinv = ldexpf(1.0f, ex - 1);
+
+        if (live) {   // ZR: d_raw as a tile (channels 0..3 in half 0, registers 0..3)
+            f32x16 zr[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zr[0][r] = 0.f;
+            if (h == 0) { zr[0][0] = dr.x; zr[0][1] = dr.y; zr[0][2] = dr.z; zr[0][3] = dr.w; }
+            store_tiles<1>(Z + TL.z_ZR * 1024, zr, lane);
+        }
+        u32x4 bh[NT][2], bl[NT][2];
+        f32x16 acc[NT];
+        // ---- rgb_linear backward (fp32 VALU): dZ_v = (W_rgb^T d_rgb) * [hv > 0]; operands of the views^T part
+        {
+            const float* wr = P + L.rgb_off;
+#pragma unroll
+            for (int t = 0; t < OTV; ++t) {
+                const f32x16 hvt = load_tile(A + (TL.a_HV + t) * 1024, lane);
+#pragma unroll
+                for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 8 * sgrp + q;
+                        const float g = wr[((0 * OTV + t) * 2 + h) * 16 + r] * dr.x + wr[((1 * OTV + t) * 2 + h) * 16 + r] * dr.y +
+                                        wr[((2 * OTV + t) * 2 + h) * 16 + r] * dr.z;
+                        const float dzv = hvt[r] > 0.f ? g : 0.f;
+                        if (live) lpZ[(TL.z_ZV + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = dzv;
+                        v[q] = dzv * S;
+                    }
+                    split8(v, bh[t][sgrp], bl[t][sgrp]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        f16_part<NT, 1, 2 * OTV, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
+        // acc = d_feature * S * 2^10: store dZ_F (unscaled), operands for feature^T
+        auto emit = [&](int slot0, const float* __restrict__ mask_base) {   // acc -> (masked) dZ: store unscaled, split scaled
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 ht;
+                if (mask_base != nullptr) ht = load_tile(mask_base + t * 1024, lane);
+#pragma unroll
+                for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 8 * sgrp + q;
+                        float x = acc[t][r] * kWInv;                        // scaled by S
+                        if (mask_base != nullptr) x = ht[r] > 0.f ? x : 0.f;
+                        if (live) lpZ[(slot0 + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = x * Sinv;
+                        v[q] = x;
+                    }
+                    split8(v, bh[t][sgrp], bl[t][sgrp]);
+                }
+            }
+        };
+        emit(TL.z_ZF, nullptr);
+        // ---- feature^T + alpha: d_h = Wf^T d_feature + w_alpha * d_sigma
+        {
+            const float* wa = P + L.alpha_off;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = wa[(t * 2 + h) * 16 + r] * (dr.w * S * kWScale);
+        }
+        f16_part<NT, 1, 2 * NT, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
+        // ---- pts_linears[D-1 .. 0]
+#pragma unroll 1
+        for (int i = L.D - 1; i >= 0; --i) {
+            emit(TL.z_Z0 + i * NT, A + (TL.a_H1 + i * NT) * 1024);       // dZ_i = d_h_{i+1} * [h_{i+1} > 0]
+            if (i == 0) break;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            f16_part<NT, 1, 2 * NT, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
+        }
     }
 }
 
@@ -397,33 +624,56 @@ extern "C" int nerfail_mlp_pack_f16(const nerfail_mlp_params* p, void* image, vo
         hipError_t e = hipMemsetAsync(image, 0, (size_t)L.total_chunks * NT * 2 * 64 * 16, s);
         if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     }
+    PackF16Table tab;
+    tab.n = p->D + 2; tab.NT = NT;
     for (int l = 0; l <= p->D + 1; ++l) {
         const bool emb = l <= p->D - 1 && layer_has_emb(l, L.skip);
-        const float* w;
-        int out_f, in_f, OT = NT, emb0 = -1, h0 = -1, dir0 = -1;
+        PackF16Desc& d = tab.l[l];
+        d.OT = NT; d.emb0 = -1; d.h0 = -1; d.dir0 = -1;
         if (l < p->D) {
             NF_REQUIRE(p->pts_w[l] != nullptr, "pts_linears pointer is NULL");
-            w = p->pts_w[l]; out_f = W;
-            in_f = (l == 0) ? kPtsCh : (emb ? W + kPtsCh : W);
-            if (emb) emb0 = 0;
-            if (l > 0) h0 = emb ? kPtsCh : 0;
+            d.w = p->pts_w[l]; d.out_f = W;
+            d.in_f = (l == 0) ? kPtsCh : (emb ? W + kPtsCh : W);
+            if (emb) d.emb0 = 0;
+            if (l > 0) d.h0 = emb ? kPtsCh : 0;
         } else if (l == p->D) {
             NF_REQUIRE(p->feature_w != nullptr, "feature_linear pointer is NULL");
-            w = p->feature_w; out_f = W; in_f = W; h0 = 0;
+            d.w = p->feature_w; d.out_f = W; d.in_f = W; d.h0 = 0;
         } else {
             NF_REQUIRE(p->views_w != nullptr, "views_linears pointer is NULL");
-            w = p->views_w; out_f = W / 2; in_f = W + kDirCh; OT = OTV; h0 = 0; dir0 = W;
+            d.w = p->views_w; d.out_f = W / 2; d.in_f = W + kDirCh; d.OT = OTV; d.h0 = 0; d.dir0 = W;
         }
         int k16 = 0;
-        if (emb0 >= 0) k16 += kEmbK16;
-        if (h0 >= 0) k16 += 2 * NT;
-        if (dir0 >= 0) k16 += kDirK16;
-        const int total = k16 * OT * 512;                // one thread per (k16-step, tile, lane, j)
-        pack_f16_layer_kernel<<<dim3((total + 255) / 256), dim3(256), 0, s>>>(
-            w, out_f, in_f, OT, NT, emb0, h0, dir0,
-            reinterpret_cast<_Float16*>(image) + (size_t)L.chunk0[l] * NT * 2 * 512, total);
-        NF_LAUNCHED("pack_f16_layer_kernel");
+        if (d.emb0 >= 0) k16 += kEmbK16;
+        if (d.h0 >= 0) k16 += 2 * NT;
+        if (d.dir0 >= 0) k16 += kDirK16;
+        d.total = k16 * d.OT * 512;                      // one element per (k16-step, tile, lane, j)
+        d.dst_halfs = (unsigned long)L.chunk0[l] * NT * 2 * 512;
     }
+    pack_f16_all_kernel<<<dim3(64, (unsigned)tab.n), dim3(256), 0, s>>>(tab, reinterpret_cast<_Float16*>(image));
+    NF_LAUNCHED("pack_f16_all_kernel");
+    return NERFAIL_OK;
+}
+
+static int launch_f16(F16Args& a, int W, hipStream_t s) {
+    const long ntiles = (a.M + 31) / 32;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > cus) blocks = cus;
+    const dim3 grid((unsigned)blocks), block(256);
+    const size_t lds = (size_t)2 * a.lay.NT * 2 * 64 * 16;          // 2-slot ring of NT*2 KB chunks
+    const bool train = a.acts != nullptr;
+    switch (W) {
+        case 256: if (train) nerf_mlp_fwd_f16_kernel<8, true><<<grid, block, lds, s>>>(a); else nerf_mlp_fwd_f16_kernel<8, false><<<grid, block, lds, s>>>(a); break;
+        case 128: if (train) nerf_mlp_fwd_f16_kernel<4, true><<<grid, block, lds, s>>>(a); else nerf_mlp_fwd_f16_kernel<4, false><<<grid, block, lds, s>>>(a); break;
+        case 64: if (train) nerf_mlp_fwd_f16_kernel<2, true><<<grid, block, lds, s>>>(a); else nerf_mlp_fwd_f16_kernel<2, false><<<grid, block, lds, s>>>(a); break;
+        default: set_error("nerfail_mlp_fwd_f16: unsupported W"); return NERFAIL_EINVAL;
+    }
+    NF_LAUNCHED("nerf_mlp_fwd_f16_kernel");
     return NERFAIL_OK;
 }
 
@@ -436,7 +686,77 @@ extern "C" int nerfail_mlp_fwd_f16(const float* packed, const void* image, int D
     if (M == 0) return NERFAIL_OK;
     NF_REQUIRE(packed && image && pts && viewdirs && raw, "NULL pointer");
     a.packed = packed; a.img = reinterpret_cast<const u32x4*>(image); a.pts = pts; a.viewdirs = viewdirs; a.raw = raw;
-    a.M = M; a.spr = samples_per_ray;
+    a.acts = nullptr; a.M = M; a.spr = samples_per_ray;
+    return launch_f16(a, W, as_stream(stream));
+}
+
+extern "C" int nerfail_mlp_fwd_f16_train(const float* packed, const void* image, int D, int W, int skip, const float* pts,
+                                         const float* viewdirs, int64_t M, int samples_per_ray, float* raw, float* acts,
+                                         void* stream) {
+    NF_REQUIRE(M >= 0, "M is negative");
+    NF_REQUIRE(samples_per_ray >= 1, "samples_per_ray must be positive");
+    F16Args a;
+    NF_REQUIRE(make_layout(D, W, skip, a.lay) && make_f16_layout(D, W, skip, a.l16), "unsupported (D, W)");
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(packed && image && pts && viewdirs && raw && acts, "NULL pointer");
+    a.packed = packed; a.img = reinterpret_cast<const u32x4*>(image); a.pts = pts; a.viewdirs = viewdirs; a.raw = raw;
+    a.acts = acts; a.M = M; a.spr = samples_per_ray;
+    return launch_f16(a, W, as_stream(stream));
+}
+
+extern "C" size_t nerfail_mlp_f16_image_T_bytes(int D, int W, int skip) {
+    F16Layout L;
+    if (!make_f16_layout(D, W, skip, L)) return 0;
+    F16LayoutT T;
+    make_f16_layout_T(D, L.NT, T);
+    return (size_t)T.total_chunks * L.NT * 2 * 64 * 16;
+}
+
+extern "C" int nerfail_mlp_pack_f16_T(const nerfail_mlp_params* p, void* image, void* stream) {
+    NF_REQUIRE(p != nullptr && image != nullptr, "NULL pointer");
+    F16Layout L;
+    NF_REQUIRE(make_f16_layout(p->D, p->W, p->skip, L), "unsupported (D, W)");
+    F16LayoutT T;
+    make_f16_layout_T(p->D, L.NT, T);
+    hipStream_t s = as_stream(stream);
+    const int W = p->W, NT = L.NT;
+    for (int part = 0; part <= p->D; ++part) {
+        const float* w;
+        int out_f, in_f, col0 = 0;
+        if (part == 0) {
+            NF_REQUIRE(p->views_w != nullptr, "views_linears pointer is NULL");
+            w = p->views_w; out_f = W / 2; in_f = W + kDirCh;
+        } else if (part == 1) {
+            NF_REQUIRE(p->feature_w != nullptr, "feature_linear pointer is NULL");
+            w = p->feature_w; out_f = W; in_f = W;
+        } else {
+            const int l = p->D - 1 - (part - 2);           // pts layer D-1 .. 1
+            NF_REQUIRE(p->pts_w[l] != nullptr, "pts_linears pointer is NULL");
+            const bool emb = layer_has_emb(l, L.skip);
+            w = p->pts_w[l]; out_f = W; in_f = emb ? W + kPtsCh : W; col0 = emb ? kPtsCh : 0;
+        }
+        const int k16 = (part == 0) ? 2 * (NT / 2) : 2 * NT;
+        const int total = k16 * NT * 512;
+        pack_f16_layer_T_kernel<<<dim3((total + 255) / 256), dim3(256), 0, s>>>(
+            w, out_f, in_f, col0, NT, reinterpret_cast<_Float16*>(image) + (size_t)T.chunk0[part] * NT * 2 * 512, total);
+        NF_LAUNCHED("pack_f16_layer_T_kernel");
+    }
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_mlp_bwd_data_f16(const float* packed, const void* imageT, int D, int W, int skip, const float* d_raw,
+                                        const float* acts, int64_t M, float* dz, void* stream) {
+    NF_REQUIRE(M >= 0, "M is negative");
+    F16BwdArgs a;
+    F16Layout L16;
+    NF_REQUIRE(make_layout(D, W, skip, a.lay) && make_f16_layout(D, W, skip, L16), "unsupported (D, W)");
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(packed && imageT && d_raw && acts && dz, "NULL pointer");
+    F16LayoutT T;
+    make_f16_layout_T(D, a.lay.NT, T);
+    a.tl = make_train_layout(D, W);
+    a.packed = packed; a.imgT = reinterpret_cast<const u32x4*>(imageT); a.d_raw = d_raw; a.acts = acts; a.dz = dz; a.M = M;
+    a.total_chunks = T.total_chunks;
     const long ntiles = (M + 31) / 32;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -446,14 +766,14 @@ extern "C" int nerfail_mlp_fwd_f16(const float* packed, const void* image, int D
     long blocks = (ntiles + 3) / 4;
     if (blocks > cus) blocks = cus;
     const dim3 grid((unsigned)blocks), block(256);
+    const size_t lds = (size_t)2 * a.lay.NT * 2 * 64 * 16;
     hipStream_t s = as_stream(stream);
-    const size_t lds = (size_t)2 * a.lay.NT * 2 * 64 * 16;          // 2-slot ring of NT*2 KB chunks
     switch (W) {
-        case 256: nerf_mlp_fwd_f16_kernel<8><<<grid, block, lds, s>>>(a); break;
-        case 128: nerf_mlp_fwd_f16_kernel<4><<<grid, block, lds, s>>>(a); break;
-        case 64: nerf_mlp_fwd_f16_kernel<2><<<grid, block, lds, s>>>(a); break;
-        default: set_error("nerfail_mlp_fwd_f16: unsupported W"); return NERFAIL_EINVAL;
+        case 256: nerf_mlp_bwd_data_f16_kernel<8><<<grid, block, lds, s>>>(a); break;
+        case 128: nerf_mlp_bwd_data_f16_kernel<4><<<grid, block, lds, s>>>(a); break;
+        case 64: nerf_mlp_bwd_data_f16_kernel<2><<<grid, block, lds, s>>>(a); break;
+        default: set_error("nerfail_mlp_bwd_data_f16: unsupported W"); return NERFAIL_EINVAL;
     }
-    NF_LAUNCHED("nerf_mlp_fwd_f16_kernel");
+    NF_LAUNCHED("nerf_mlp_bwd_data_f16_kernel");
     return NERFAIL_OK;
 }

@@ -78,3 +78,28 @@ def test_f16x3_render_matches_reference(golden):
                        perturb=1., t_rand=T(g['cfg2_t_rand']), u=T(g['cfg2_u']))
     for k in ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'z_std', 'pts_max'):
         assert rel_err(N(r[k]), g['cfg2_pert_' + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize('tag,D,W', [('small', 4, 64), ('full', 8, 256)])
+def test_f16x3_training_forward_gradients(golden, tag, D, W):
+    """Training step with the split-precision FORWARD (activations saved in fp32, backward kernels unchanged):
+    loss and parameter gradients vs the reference's autograd, same bounds as tests/test_hip_train.py."""
+    from conftest import l2_err
+    from nerfail_amd import run_nerf as RN
+    g = golden('g7_train_grads')
+    _, coarse = hip_nerf(D, W, 31, requires_grad=True, precision='f16x3')
+    _, fine = hip_nerf(D, W, 32, requires_grad=True, precision='f16x3')
+    r = RN.render_rays(T(g[tag + '_rays']), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True,
+                       perturb=1., t_rand=T(g[tag + '_t_rand']), u=T(g[tag + '_u']))
+    target = T(g[tag + '_target'])
+    loss = RN.img2mse(r['rgb_map'], target) + RN.img2mse(r['rgb0'], target)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[tag + '_loss'])) < 1e-5 * abs(float(g[tag + '_loss']))
+    for nm, net in (('coarse', coarse), ('fine', fine)):
+        for k, p in net.named_parameters():
+            got = N(p.grad)
+            if tag == 'small':
+                assert l2_err(got, g['small_%s_grad_%s' % (nm, k)]) < 5e-3, (nm, k)
+            else:
+                refn = float(g['full_%s_gradnorm_%s' % (nm, k)])
+                assert abs(np.linalg.norm(got.astype(np.float64)) - refn) < 5e-3 * refn, (nm, k)

@@ -40,7 +40,7 @@ def timeit(fn, reps=10):
 
 def main():
     m = net(1)
-    for R, N in ((1024, 192), (8192, 192), (65536, 192)):
+    for R, N in ((1024, 64), (1024, 192), (8192, 192)):
         M = R * N
         pts = torch.randn((R, N, 3), device=dev)
         vd = torch.nn.functional.normalize(torch.randn((R, 3), device=dev), dim=-1)
@@ -70,7 +70,20 @@ def main():
         def f_bw():
             _lib.check(lib.nerfail_mlp_bwd_weights(m.D, m.W, m._skip(), _lib.dev(acts), _lib.dev(dz), M,
                                                    _train._grads_struct(m, grads), _lib.stream()))
-        for name, fn in (('fwd_infer', f_inf), ('fwd_f16x3', f_f16), ('fwd_train', f_train), ('bwd_data', f_bd), ('bwd_weights', f_bw)):
+        pk16T = _train.packed_f16_T(m16)
+
+        def f_train16():
+            _train.mlp_fwd_train(m16, pts, vd)
+
+        def f_bd16():
+            _lib.check(lib.nerfail_mlp_bwd_data_f16(_lib.dev(pk), _lib.dev(pk16T), m.D, m.W, m._skip(), _lib.dev(d_raw),
+                                                    _lib.dev(acts), M, _lib.dev(dz), _lib.stream()))
+
+        def f_bw16():
+            _lib.check(lib.nerfail_mlp_bwd_weights_bf16x3(m.D, m.W, m._skip(), _lib.dev(acts), _lib.dev(dz), M,
+                                                          _train._grads_struct(m, grads), _lib.stream()))
+        for name, fn in (('fwd_infer', f_inf), ('fwd_f16x3', f_f16), ('fwd_train', f_train), ('fwd_train_f16', f_train16),
+                         ('bwd_data_f16', f_bd16), ('bwd_w_bf16x3', f_bw16), ('bwd_data', f_bd), ('bwd_weights', f_bw)):
             med, mn = timeit(fn)
             print('M=%7d %-12s median %8.3f ms  min %8.3f ms  -> %6.1f TFLOP/s (fwd-equivalent FLOPs)' %
                   (M, name, med, mn, M * FLOP / (med * 1e-3) / 1e12), flush=True)
