@@ -268,24 +268,26 @@ __device__ __forceinline__ void dw_task(const WArgs& a, const WTask tk, int lane
 // ---- split-precision form of the same task (opt-in, WArgs::bf16x3): the operands are converted IN REGISTERS to bf16
 // hi / lo pairs (a = a_hi + a_lo, 16 significant bits, fp32's exponent range - so no scaling is needed for gradients of
 // any magnitude) and every product block is ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16: 3 MFMAs of 32 cycles
-// per 16 samples instead of 8 f32 MFMAs of 64 cycles. ~1.5e-5 relative per product, far inside what a stochastic
-// gradient needs (and the 5e-3 parity bound). k16-step mapping: (step ks, half kh, element j) <-> sample 16*ks + 8*kh + j,
+// per 16 samples instead of 8 f32 MFMAs of 64 cycles. The dropped lo*lo term is ~2^-16 relative per product. k16-step mapping: (step ks, half kh, element j) <-> sample 16*ks + 8*kh + j,
 // i.e. each lane reads 8 contiguous floats (two 16-byte loads) per operand and step.
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// a = hi + lo + O(2^-18 |a|), both halves rounded to nearest (v_cvt_pk_bf16_f32, two elements per instruction): the
+// residual is unbiased - a truncating split leaves every product short by the same sign, which does not average out
+// over the non-negative post-ReLU activations.
 __device__ __forceinline__ void split_bf16(const f32x4& v0, const f32x4& v1, u32x4b& hi, u32x4b& lo) {
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    unsigned hb[8], lb[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        hb[i] = __float_as_uint(v[i]) & 0xffff0000u;                      // bf16(a), truncated
-        lb[i] = __float_as_uint(v[i] - __uint_as_float(hb[i]));           // exact residual, truncated to bf16 below
-    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {                                         // element 2p in the low half, 2p+1 in the high half
-        hi[p] = (hb[2 * p] >> 16) | hb[2 * p + 1];
-        lo[p] = (lb[2 * p] >> 16) | (lb[2 * p + 1] & 0xffff0000u);
+        const f32x2 x = {v[2 * p], v[2 * p + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf2));
+        const f32x2 r = {x[0] - __uint_as_float(hu << 16), x[1] - __uint_as_float(hu & 0xffff0000u)};
+        hi[p] = hu;
+        lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf2));
     }
 }
 

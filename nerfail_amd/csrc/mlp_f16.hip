@@ -517,12 +517,19 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
         float* __restrict__ lpZ = Z + (lane >> 5) * 128 + (lane & 31);
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live && sraw < a.M) dr = reinterpret_cast<const float4*>(a.d_raw)[sraw];
-        // exact power-of-two scale of this wave's gradients: max |d_raw| -> [1, 2)
-        float smax = wave_max(fmaxf(fmaxf(fabsf(dr.x), fabsf(dr.y)), fmaxf(fabsf(dr.z), fabsf(dr.w))));
-        int ex = 0;
-        if (smax > 0.f) (void)frexpf(smax, &ex);                           // smax = m * 2^ex, m in [0.5, 1)
-        const float S = ldexpf(1.0f, 1 - ex), Sinv = ldexpf(1.0f, ex - 1);
-
+        // Exact power-of-two scale PER SAMPLE (a sample is a column of the B operand, so scaling it scales the same
+        // column of the result), renewed at every layer: gradients shrink from layer to layer and differ by orders
+        // of magnitude between the samples of a ray, and an fp16 lo half below 2^-14 loses its bits to the subnormal
+        // grid. A fixed per-wave scale cost a factor ~2 of gradient accuracy per layer (tools/grad_accuracy.py).
+        int E = 0;                                                         // S = 2^E, kept inside [2^-100, 2^100]
+        {
+            const float m = fmaxf(fmaxf(fabsf(dr.x), fabsf(dr.y)), fmaxf(fabsf(dr.z), fabsf(dr.w)));
+            int ex = 10;
+            if (m > 0.f) (void)frexpf(m, &ex);                             // m = f * 2^ex, f in [0.5, 1)
+            E = 10 - ex;                                                   // max |d_raw| -> [2^9, 2^10): 2^6 of headroom for W_rgb
+            E = E > 100 ? 100 : (E < -100 ? -100 : E);
+        }
+        float S = ldexpf(1.0f, E), Sinv = ldexpf(1.0f, -E);
         if (live) {   // ZR: d_raw as a tile (channels 0..3 in half 0, registers 0..3)
             f32x16 zr[1];
 #pragma unroll
@@ -560,25 +567,42 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         f16_part<NT, 1, 2 * OTV, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
         // acc = d_feature * S * 2^10: store dZ_F (unscaled), operands for feature^T
-        auto emit = [&](int slot0, const float* __restrict__ mask_base) {   // acc -> (masked) dZ: store unscaled, split scaled
+        auto emit = [&](int slot0, const float* __restrict__ mask_base) {   // acc -> (masked) dZ: store unscaled, split rescaled
+            float m = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 ht;
                 if (mask_base != nullptr) ht = load_tile(mask_base + t * 1024, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float x = acc[t][r] * kWInv;                            // dZ * S
+                    if (mask_base != nullptr) x = ht[r] > 0.f ? x : 0.f;
+                    acc[t][r] = x;
+                    m = fmaxf(m, fabsf(x));
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));                                // the two lanes holding this sample's channels
+            int ex = 14;                                                    // all-zero sample: keep the scale
+            if (m > 0.f) (void)frexpf(m, &ex);
+            int k = 14 - ex;                                                // sample max -> [2^13, 2^14)
+            k = E + k > 100 ? 100 - E : (E + k < -100 ? -100 - E : k);
+            E += k;
+            const float up = ldexpf(1.0f, k), Sinv_old = Sinv;
+            S = ldexpf(1.0f, E); Sinv = ldexpf(1.0f, -E);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int sgrp = 0; sgrp < 2; ++sgrp) {
                     float v[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int r = 8 * sgrp + q;
-                        float x = acc[t][r] * kWInv;                        // scaled by S
-                        if (mask_base != nullptr) x = ht[r] > 0.f ? x : 0.f;
-                        if (live) lpZ[(slot0 + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = x * Sinv;
-                        v[q] = x;
+                        const float x = acc[t][r];
+                        if (live) lpZ[(slot0 + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = x * Sinv_old;
+                        v[q] = x * up;
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
                 }
-            }
         };
         emit(TL.z_ZF, nullptr);
         // ---- feature^T + alpha: d_h = Wf^T d_feature + w_alpha * d_sigma

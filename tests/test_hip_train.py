@@ -97,7 +97,7 @@ def test_training_loop_adam_reduces_loss():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0] and np.isfinite(losses).all()
 
 
