@@ -177,9 +177,9 @@ __device__ __forceinline__ void dw_task(const WArgs& a, const WTask tk, int lane
     // out): a conditional load makes hipcc branch around it and wait vmcnt(0), which kills the software pipeline.
     int offA[MA], offB[NB];
 #pragma unroll
-    for (int m = 0; m < MA; ++m) offA[m] = (d.dz_slot0 + 4 * tk.ob + m) * 1024 + c * 32 + 16 * kh;
+    for (int m = 0; m < MA; ++m) offA[m] = (d.dz_slot0 + 4 * tk.ob + m) * 1024 + kh * 512 + c * kSlotCh;
 #pragma unroll
-    for (int n = 0; n < NB; ++n) offB[n] = (xp.slot0 + 4 * tk.ib + n) * 1024 + c * 32 + 16 * kh;
+    for (int n = 0; n < NB; ++n) offB[n] = (xp.slot0 + 4 * tk.ib + n) * 1024 + kh * 512 + c * kSlotCh;
     f32x16 acc[MA][NB];
 #pragma unroll
     for (int m = 0; m < MA; ++m)
@@ -298,9 +298,9 @@ __device__ __forceinline__ void dw_task_bf16(const WArgs& a, const WTask tk, int
     const int c = lane & 31, kh = lane >> 5;
     int offA[MA], offB[NB];
 #pragma unroll
-    for (int m = 0; m < MA; ++m) offA[m] = (d.dz_slot0 + 4 * tk.ob + m) * 1024 + c * 32 + 8 * kh;
+    for (int m = 0; m < MA; ++m) offA[m] = (d.dz_slot0 + 4 * tk.ob + m) * 1024 + c * kSlotCh + 8 * kh;
 #pragma unroll
-    for (int n = 0; n < NB; ++n) offB[n] = (xp.slot0 + 4 * tk.ib + n) * 1024 + c * 32 + 8 * kh;
+    for (int n = 0; n < NB; ++n) offB[n] = (xp.slot0 + 4 * tk.ib + n) * 1024 + c * kSlotCh + 8 * kh;
     f32x16 acc[MA][NB];
 #pragma unroll
     for (int m = 0; m < MA; ++m)
@@ -329,12 +329,12 @@ __device__ __forceinline__ void dw_task_bf16(const WArgs& a, const WTask tk, int
             // prefetch the next k16-step (step 1 of this tile, or step 0 of the next tile)
 #pragma unroll
             for (int m = 0; m < MA; ++m) {
-                const float* src = (ks == 0) ? zb + offA[m] + 16 : zn + offA[m];
+                const float* src = (ks == 0) ? zb + offA[m] + 512 : zn + offA[m];
                 na[m][0] = *reinterpret_cast<const f32x4*>(src); na[m][1] = *reinterpret_cast<const f32x4*>(src + 4);
             }
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
-                const float* src = (ks == 0) ? xb + offB[n] + 16 : xn + offB[n];
+                const float* src = (ks == 0) ? xb + offB[n] + 512 : xn + offB[n];
                 nb[n][0] = *reinterpret_cast<const f32x4*>(src); nb[n][1] = *reinterpret_cast<const f32x4*>(src + 4);
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
         float* __restrict__ lpA = nullptr;                           // lane pointer for accumulator-layout stores
         if (TRAIN && save) {
             A = a.acts + (size_t)tile * ((3 + (L.D + 1) * NT + NT / 2) * 1024);
-            lpA = A + (lane >> 5) * 128 + (lane & 31);
+            lpA = A + acc_lane_off(lane);
             store_enc<10, 32>(A, emb, lane);
             store_enc<4, 16>(A + 2 * 1024, demb, lane);
         }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
                         v[q] = relu ? fmaxf(x, 0.f) : x;
                         if (TRAIN && save) {
                             const int r = 8 * sgrp + q;
-                            lpA[(slot0 + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = v[q];
+                            lpA[(slot0 + t) * 1024 + acc_reg_off(r)] = v[q];
                         }
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
             for (int t = 0; t < OTV; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    lpA[(3 + (L.D + 1) * NT + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = fmaxf(hv[t][r] * kWInv, 0.f);
+                    lpA[(3 + (L.D + 1) * NT + t) * 1024 + acc_reg_off(r)] = fmaxf(hv[t][r] * kWInv, 0.f);
         }
         // ---- rgb_linear on VALU (fp32)
         const float* wr = P + L.rgb_off;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
         const long sraw = tl_ * 32 + j;
         const float* __restrict__ A = a.acts + (size_t)tl_ * TL.a_slots * 1024;
         float* __restrict__ Z = a.dz + (size_t)tl_ * TL.z_slots * 1024;
-        float* __restrict__ lpZ = Z + (lane >> 5) * 128 + (lane & 31);
+        float* __restrict__ lpZ = Z + acc_lane_off(lane);
         float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live && sraw < a.M) dr = reinterpret_cast<const float4*>(a.d_raw)[sraw];
         // Exact power-of-two scale PER SAMPLE (a sample is a column of the B operand, so scaling it scales the same
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
                         const float g = wr[((0 * OTV + t) * 2 + h) * 16 + r] * dr.x + wr[((1 * OTV + t) * 2 + h) * 16 + r] * dr.y +
                                         wr[((2 * OTV + t) * 2 + h) * 16 + r] * dr.z;
                         const float dzv = hvt[r] > 0.f ? g : 0.f;
-                        if (live) lpZ[(TL.z_ZV + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = dzv;
+                        if (live) lpZ[(TL.z_ZV + t) * 1024 + acc_reg_off(r)] = dzv;
                         v[q] = dzv * S;
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
                     for (int q = 0; q < 8; ++q) {
                         const int r = 8 * sgrp + q;
                         const float x = acc[t][r];
-                        if (live) lpZ[(slot0 + t) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = x * Sinv_old;
+                        if (live) lpZ[(slot0 + t) * 1024 + acc_reg_off(r)] = x * Sinv_old;
                         v[q] = x * up;
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);

@@ -163,52 +163,75 @@ __device__ __forceinline__ void relu_to(f32x16 (&dst)[NT], const f32x16 (&src)[N
         for (int r = 0; r < 16; ++r) dst[t][r] = relu ? fmaxf(src[t][r], 0.f) : src[t][r];
 }
 
-// store / load accumulator-layout tiles to / from channel-major slots: one dword instruction per register = two
-// full 128-byte rows per wave instruction. Every address is "ONE per-lane pointer + compile-time constant":
+// A saved slot (1024 floats) is [2 halves of 16 samples][32 channels][16 samples]: element (channel ch, sample j) lives
+// at slot_pos(j) + 16*ch. One k16-step of the weight-gradient GEMM (k = sample) is then a contiguous 2 KB half slot
+// (every 128-byte line is consumed completely by the step that touches it), and an accumulator register still
+// stores as four full 64-byte segments per wave instruction.
+__device__ __forceinline__ int slot_pos(int j) { return (j >> 4) * 512 + (j & 15); }
+constexpr int kSlotCh = 16;                // floats between consecutive channels
+
+// store / load accumulator-layout tiles to / from channel-major slots: one dword instruction per register.
+// Every address is "ONE per-lane pointer + compile-time constant":
 // acc_channel(r, h) = const(r) + 4h and enc_channel(s, h) = const(s) + 3h, so the half-dependent part lives in the
 // lane pointer and the rest folds into the instruction's immediate offset (computed per access, the addresses
 // otherwise get hoisted, spilled, and every store ends up behind a vmcnt(0)).
+__device__ __forceinline__ int acc_lane_off(int lane) { return slot_pos(lane & 31) + (lane >> 5) * 4 * kSlotCh; }
+__device__ __forceinline__ constexpr int acc_reg_off(int r) { return ((r & 3) + 8 * (r >> 2)) * kSlotCh; }
+
 template <int NTILES>
 __device__ __forceinline__ void store_tiles(float* __restrict__ base, const f32x16 (&a)[NTILES], int lane) {
-    float* __restrict__ lp = base + (lane >> 5) * 128 + (lane & 31);
+    float* __restrict__ lp = base + acc_lane_off(lane);
 #pragma unroll
     for (int t = 0; t < NTILES; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lp[t * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = a[t][r];
+        for (int r = 0; r < 16; ++r) lp[t * 1024 + acc_reg_off(r)] = a[t][r];
 }
 __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int lane) {
-    const float* __restrict__ lp = base + (lane >> 5) * 128 + (lane & 31);
+    const float* __restrict__ lp = base + acc_lane_off(lane);
     f32x16 v;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = lp[((r & 3) + 8 * (r >> 2)) * 32];
+    for (int r = 0; r < 16; ++r) v[r] = lp[acc_reg_off(r)];
     return v;
 }
 // positional-encoding k-step values (per lane: step s -> channel enc_channel(s, h)) <-> channel-major slots.
 // BANDS = 10 (pts: 63 channels in 2 slots) or 4 (dirs: 27 channels in 1 slot); padding channels are zero-filled so
-// the weight-gradient kernel never reads uninitialised memory.
+// the weight-gradient kernel never reads uninitialised memory. Channel c of an encoding lives in slot c / 32.
+__device__ __forceinline__ constexpr int enc_ch_off(int c) { return (c >> 5) * 1024 + (c & 31) * kSlotCh; }
+
 template <int BANDS, int NSTEPS>
 __device__ __forceinline__ void store_enc(float* __restrict__ base, const float (&e)[NSTEPS], int lane) {
     const int h = lane >> 5, j = lane & 31;
-    float* __restrict__ lp3 = base + h * 96 + j;       // + 3h channels
+    float* __restrict__ lpz = base + slot_pos(j);
+    float* __restrict__ lp3 = lpz + h * 3 * kSlotCh;   // + 3h channels
+    // channel 29 (+3h) is the one pair that straddles the slot boundary (29 | 32): its own per-lane pointer
+    float* __restrict__ lpx = lpz + (h ? enc_ch_off(32) : enc_ch_off(29));
 #pragma unroll
-    for (int s = 0; s < 3 * BANDS; ++s) lp3[(3 + 6 * (s / 3) + (s % 3)) * 32] = e[s];
-    base[h * 32 + j] = e[3 * BANDS];                   // x | y  (channels 0, 1)
+    for (int s = 0; s < 3 * BANDS; ++s) {
+        const int c0 = 3 + 6 * (s / 3) + (s % 3);
+        if (c0 == 29) lpx[0] = e[s];
+        else lp3[enc_ch_off(c0)] = e[s];
+    }
+    lpz[h * kSlotCh] = e[3 * BANDS];                   // x | y  (channels 0, 1)
     constexpr int nch = 3 + 6 * BANDS, cap = ((nch + 31) / 32) * 32;
     // half 0: z (channel 2) and the even padding channels; half 1: the odd padding channels
-    float* __restrict__ lpz = base + j;
-    if (h == 0) lpz[2 * 32] = e[3 * BANDS + 1];
+    if (h == 0) lpz[2 * kSlotCh] = e[3 * BANDS + 1];
 #pragma unroll
     for (int c = nch; c < cap; ++c)
-        if (((c - nch) & 1) == h) lpz[c * 32] = 0.f;
+        if (((c - nch) & 1) == h) lpz[enc_ch_off(c)] = 0.f;
 }
 template <int BANDS, int NSTEPS>
 __device__ __forceinline__ void load_enc(const float* __restrict__ base, float (&e)[NSTEPS], int lane) {
     const int h = lane >> 5, j = lane & 31;
-    const float* __restrict__ lp3 = base + h * 96 + j;
+    const float* __restrict__ lpz = base + slot_pos(j);
+    const float* __restrict__ lp3 = lpz + h * 3 * kSlotCh;
+    const float* __restrict__ lpx = lpz + (h ? enc_ch_off(32) : enc_ch_off(29));
 #pragma unroll
-    for (int s = 0; s < 3 * BANDS; ++s) e[s] = lp3[(3 + 6 * (s / 3) + (s % 3)) * 32];
-    e[3 * BANDS] = base[h * 32 + j];
-    const float z = base[2 * 32 + j];
+    for (int s = 0; s < 3 * BANDS; ++s) {
+        const int c0 = 3 + 6 * (s / 3) + (s % 3);
+        e[s] = (c0 == 29) ? lpx[0] : lp3[enc_ch_off(c0)];
+    }
+    e[3 * BANDS] = lpz[h * kSlotCh];
+    const float z = lpz[2 * kSlotCh];
     e[3 * BANDS + 1] = h ? 0.f : z;
 #pragma unroll
     for (int s = 3 * BANDS + 2; s < NSTEPS; ++s) e[s] = 0.f;

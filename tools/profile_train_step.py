@@ -45,3 +45,17 @@ for it in range(12):
         for k, v in (('pack', t1 - t0), ('forward', t2 - t1), ('zero_grad', t3 - t2), ('backward', t4 - t3), ('adam', t5 - t4)):
             T.setdefault(k, []).append(v * 1e3)
 print(prec, {k: round(float(np.median(v)), 3) for k, v in T.items()}, 'sum', round(sum(float(np.median(v)) for v in T.values()), 3))
+# free-running steps (no synchronisation inside): the real step time, to compare with the kernel-time sum of a
+# `rocprofv3 --kernel-trace --stats` run of this script
+NFREE = 20
+t0 = sync()
+for it in range(NFREE):
+    t_rand = torch.rand((1024, 64), device=dev); u = torch.rand((1024, 128), device=dev)
+    r = RN.render_rays(rays, coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1., t_rand=t_rand, u=u)
+    loss = RN.img2mse(r['rgb_map'], target) + RN.img2mse(r['rgb0'], target)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+t_host = time.perf_counter()
+t1 = sync()
+print('free-running: %.3f ms/step wall, host enqueue %.3f ms/step' % ((t1 - t0) / NFREE * 1e3, (t_host - t0) / NFREE * 1e3))
