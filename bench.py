@@ -82,7 +82,8 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     params = list(coarse.parameters()) + list(fine.parameters())
     for p in params:
         p.requires_grad_(True)
-    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    from nerfail_amd.optim import Adam
+    opt = Adam(params, lr=5e-4, betas=(0.9, 0.999))              # RN:207 on the fused K13 kernel
     focal, K = synth.lego_intrinsics(H, W)
     c2w = synth.pose_spherical(-180., -30., 4.)[:3, :4]
     all_rays = ray_gen(H, W, K, c2w, 2., 6.)

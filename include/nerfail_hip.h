@@ -244,6 +244,25 @@ int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* gra
 int nerfail_igsm_step(const float* spatial, const float* grad, const float* spatial_init, int64_t n,
                       float a, float epsilon, int targeted, float* out, void* stream);
 
+/* K13 - one optimizer step of the NeRF training loop for ALL parameter tensors in one launch. Replaces
+ * optimizer.step() of torch.optim.Adam(params, lr, betas=(0.9, 0.999)) (run_nerf.py:207, :792): no weight decay, no
+ * amsgrad. Same fp32 operation order as torch's CPU kernels (bit-exact but for rare 1-ulp differences, fixture g13):
+ *   m <- fma(1-beta1, g - m, m);  v <- fma((1-beta2) g, g, beta2 v);
+ *   p <- p + (-step_size m) / (sqrt(v) / bias_correction2_sqrt + eps)
+ * step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) are computed by the caller in double
+ * (per tensor: torch keeps one step counter per parameter). `tensors` is a HOST array, copied at enqueue. */
+typedef struct nerfail_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    float step_size;
+    float bias_correction2_sqrt;
+} nerfail_adam_tensor;
+int nerfail_adam_step(const nerfail_adam_tensor* tensors, int n_tensors, double beta1, double beta2, double eps,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

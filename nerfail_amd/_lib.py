@@ -77,7 +77,16 @@ SIGNATURES = {
     'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
     'nerfail_igsm_step': (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p]),
+    'nerfail_adam_step': (c_i, [c_p, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_p]),
 }
+
+
+
+class AdamTensor(ctypes.Structure):
+    """struct nerfail_adam_tensor (include/nerfail_hip.h)"""
+    _fields_ = [('param', c_p), ('grad', c_p), ('exp_avg', c_p), ('exp_avg_sq', c_p), ('numel', c_i64),
+                ('step_size', c_f), ('bias_correction2_sqrt', c_f)]
+
 
 _lib = None
 

@@ -18,6 +18,7 @@
 //     A wave owns a 128 x 128 block of one layer's dW (4x4 accumulator tiles, 256 registers) over a chunk of
 //     sample tiles and adds it to the gradient with float atomics shaped as two 128-byte runs per instruction;
 //     bias gradients fall out of the A operands (row sums) for free.
+#include <cstdlib>
 #include "mlp_layout.h"
 
 namespace nerfail {
@@ -442,6 +443,186 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_kernel(WArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------- LDS-staged bf16x3 weight gradients
+// The register-fed kernel above leaves the bf16 MFMAs waiting: a wave can keep only one k16-step of fp32 operands in
+// flight next to its 256 accumulator registers (16 KB, ~64 KB per CU - latency bound), the two waves that share an
+// operand tile fetch it separately, and each instruction touches 32 half-lines. Here (W = 256 only) a workgroup owns
+// one whole layer-part at a time ("group": an LA-tile run of dZ slots x an LB-tile run of activation slots, split
+// evenly over its 4 waves as MA x NB blocks) and every operand tile is fetched ONCE per workgroup, straight into LDS
+// by LDS-DMA (global_load_lds_dwordx4: 1 KB = 16 full 64-byte channel rows per wave instruction, no VGPRs), through a
+// 4-stage ring of k16-steps: 3 stages = 96 KB per CU stay in flight behind the step being multiplied. One raw
+// s_barrier per step; LDS-DMA completion is counted with s_waitcnt vmcnt(2G) so the younger stages keep flying
+// across the barrier (a __syncthreads() would drain them).
+//   LDS image of a slot-step (2 KB = [32 channels][16 samples] fp32): the DMA writes lane-linear (wave base + 16 B x
+// lane), so the XOR swizzle that makes the readers' ds_read_b128 conflict-free is applied to the per-lane SOURCE
+// address: 16-byte piece (channel c, quarter q) sits at position 4c + (q ^ ((c >> 2) & 3)). A reader lane (c, kh)
+// takes quarters 2kh and 2kh+1 = samples 8kh .. 8kh+7 of the step, exactly dw_task_bf16's k mapping.
+#ifndef NF_DW_ABLATE
+#define NF_DW_ABLATE 0          // timing experiments (tools/ablate_dw.py): 1 no LDS-DMA, 2 no hi/lo split, 3 no MFMA
+#endif
+#ifndef NF_DW_AUX
+#define NF_DW_AUX 0             // cache policy bits of the LDS-DMA loads (2 = nt)
+#endif
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+struct LGroup { int desc, part, dz_slot0, x_slot0, shape; };
+constexpr int kMaxLGroups = 16, kLdsStages = 4, kLdsStageFloats = 8192;      // 4 x 32 KB
+struct LArgs {
+    const float* acts;
+    const float* dz;
+    long ntiles;
+    int a_slots, z_slots, ngroups;
+    int cost[kMaxLGroups];                 // estimated cycles per k16-step (MFMA + staging), for the partition
+    long cum[kMaxLGroups + 1];
+    LGroup grp[kMaxLGroups];
+    LinDesc desc[kMaxDesc];
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MA, int NB, int LA, int LB>
+__device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, float* smem, int lane, int wave,
+                                             long t_begin, long t_end) {
+    constexpr int NPIECE = 2 * (LA + LB), G = (NPIECE + 3) / 4, NS = kLdsStages;
+    constexpr int NBK = LB / NB;
+    static_assert((LA / MA) * NBK == 4 && LA % MA == 0 && LB % NB == 0, "a group is split evenly over 4 waves");
+    static_assert(G >= 2 && G * 1024 <= kLdsStageFloats, "stage does not fit");
+    const LinDesc& d = a.desc[g.desc];
+    const XPart& xp = d.parts[g.part];
+    const int a0 = (wave / NBK) * MA, b0 = (wave % NBK) * NB;           // this wave's block: A tiles a0.., B tiles b0..
+    const int c = lane & 31, kh = lane >> 5;
+    const int p0 = 4 * c + ((2 * kh) ^ ((c >> 2) & 3));
+    const int rd0 = p0 * 4, rd1 = (p0 ^ 1) * 4;                         // float offsets of the two quarters inside a slot-step
+    // DMA source: this wave moves pieces wave, wave+4, ... (all of parity wave&1 = channel half of the slot-step)
+    const int cs = (wave & 1) * 16 + (lane >> 2);
+    const int lane_src = cs * kSlotCh + (((lane & 3) ^ ((cs >> 2) & 3)) * 4);
+    f32x16 acc[MA][NB];
+#pragma unroll
+    for (int m = 0; m < MA; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    float rowsum[MA];
+#pragma unroll
+    for (int m = 0; m < MA; ++m) rowsum[m] = 0.f;
+    const bool do_bias = (d.gb != nullptr) && g.part == 0 && b0 == 0;
+    const long S = 2 * (t_end - t_begin);                               // k16-steps of this segment
+    if (S <= 0) return;                                                 // workgroup-uniform
+
+    auto issue = [&](long s, int rs) {                                  // stage s -> ring slot rs (steps past the end re-read the last one: uniform vmcnt)
+        const long sc = s < S ? s : S - 1;
+        const long t = t_begin + (sc >> 1);
+        const int ks = (int)(sc & 1);
+        const float* __restrict__ zb = a.dz + ((size_t)t * a.z_slots + g.dz_slot0) * 1024 + ks * 512 + lane_src;
+        const float* __restrict__ xb = a.acts + ((size_t)t * a.a_slots + g.x_slot0) * 1024 + ks * 512 + lane_src;
+        float* dst = smem + rs * kLdsStageFloats;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int pc = wave + 4 * i;
+            const int ps = pc < NPIECE ? pc : pc - 4;                   // padding piece: same parity, valid source
+            const float* src = ps < 2 * LA ? zb + (ps >> 1) * 1024 : xb + ((ps - 2 * LA) >> 1) * 1024;
+            if (NF_DW_ABLATE == 4)      // timing experiment: plane-major addressing [slot][tile] (wrong data, in bounds)
+                src = ps < 2 * LA ? a.dz + ((size_t)(g.dz_slot0 + (ps >> 1)) * a.ntiles + t) * 1024 + ks * 512 + lane_src
+                                  : a.acts + ((size_t)(g.x_slot0 + ((ps - 2 * LA) >> 1)) * a.ntiles + t) * 1024 + ks * 512 + lane_src;
+            if (NF_DW_ABLATE != 1) __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + pc * 256), 16, 0, NF_DW_AUX);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, s);
+    int rs_read = 0, rs_issue = NS - 1;
+    for (long s = 0; s < S; ++s) {
+        wait_vmcnt<(NS - 2) * G>();                                     // this wave's pieces of stage s have landed
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's have; and stage s-1 is no longer read
+        issue(s + NS - 1, rs_issue);
+        const float* __restrict__ st = smem + rs_read * kLdsStageFloats;
+        u32x4b ah[MA], al[MA], bh[NB], bl[NB];
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd0);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd1);
+            if (NF_DW_ABLATE == 2) { ah[m] = __builtin_bit_cast(u32x4b, v0); al[m] = __builtin_bit_cast(u32x4b, v1); }
+            else split_bf16(v0, v1, ah[m], al[m]);
+            if (do_bias) rowsum[m] += (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd0);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd1);
+            if (NF_DW_ABLATE == 2) { bh[n] = __builtin_bit_cast(u32x4b, v0); bl[n] = __builtin_bit_cast(u32x4b, v1); }
+            else split_bf16(v0, v1, bh[n], bl[n]);
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int m = 0; m < MA; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const bf8 A_ = __builtin_bit_cast(bf8, x == 2 ? al[m] : ah[m]);
+                    const bf8 B_ = __builtin_bit_cast(bf8, x == 1 ? bl[n] : bh[n]);
+                    if (NF_DW_ABLATE != 3) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[m][n], 0, 0, 0);
+                    else acc[m][n][(x * 5 + m + n) & 15] += __uint_as_float(A_[0] == B_[1] ? 1u : 0u);   // keep the operands alive
+                }
+        rs_read = (rs_read + 1) & (NS - 1);
+        rs_issue = (rs_issue + 1) & (NS - 1);
+    }
+    wait_vmcnt<0>();                                                    // drain the padding stages before the ring is reused
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int m = 0; m < MA; ++m) {
+        const int tt = a0 + m;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int col = 32 * (b0 + n) + c;
+            if (col >= xp.ncols) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * tt + acc_channel(r, kh);
+                if (row >= d.row0 && row < d.row1)
+                    atomicAdd(d.gw + (long)(row - d.row0) * d.in_f + xp.col0 + col, acc[m][n][r]);
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+            const float sres = rowsum[m] + __shfl_xor(rowsum[m], 32, 64);
+            const int row = 32 * (a0 + m) + c;
+            if (kh == 0 && row >= d.row0 && row < d.row1) atomicAdd(d.gb + (row - d.row0), sres);
+        }
+    }
+}
+
+// group shapes of a W = 256 network: <MA, NB, LA, LB>
+//   0 full 256x256 layer-part <4,4,8,8>   1 views (128 x 256) <4,2,4,8>   2 encoding columns (256 x 63) <2,2,8,2>
+//   3 view-direction columns (128 x 27) <1,1,4,1>   4 rgb head (3 x 128) <1,1,1,4>   5 alpha head (1 x 256) <1,2,1,8>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_lds_kernel(LArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[kLdsStages * kLdsStageFloats];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long total = a.cum[a.ngroups];
+    const long lo = total / gridDim.x * blockIdx.x + (total % gridDim.x) * blockIdx.x / gridDim.x;
+    const long hi = total / gridDim.x * (blockIdx.x + 1) + (total % gridDim.x) * (blockIdx.x + 1) / gridDim.x;
+    for (int g = 0; g < a.ngroups; ++g) {
+        const long g0 = a.cum[g], g1 = a.cum[g + 1];
+        if (hi <= g0 || lo >= g1) continue;
+        const long cst = a.cost[g];
+        const long s_ = (lo > g0 ? lo : g0) - g0, e_ = (hi < g1 ? hi : g1) - g0;
+        const long t_begin = (s_ + cst - 1) / cst, t_end = (e_ + cst - 1) / cst;
+        if (t_begin >= t_end) continue;
+        const LGroup& grp = a.grp[g];
+        switch (grp.shape) {
+            case 0: dw_group_lds<4, 4, 8, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 1: dw_group_lds<4, 2, 4, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 2: dw_group_lds<2, 2, 8, 2>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 3: dw_group_lds<1, 1, 4, 1>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 4: dw_group_lds<1, 1, 1, 4>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            default: dw_group_lds<1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
+        }
+    }
+}
+
 static int cu_count() {
     static int cus = 0;
     if (cus == 0) {
@@ -591,6 +772,45 @@ static int bwd_weights_impl(int D, int W, int skip, const float* acts, const flo
         part(d, TL.a_H1 + (D - 1) * NT, NT, 0, 0, W);
     }
     a.ndesc = nd;
+    // NERFAIL_DW_KERNEL=lds selects the LDS-staged kernel. It is NOT faster: both kernels move the same 4.3 GB per
+    // 196 608 samples and both sit at the ~4 TB/s this access pattern gets from HBM (measured 1.12 vs 1.21 ms;
+    // without its loads the LDS kernel needs 0.42 ms). Kept as the tested starting point for when the bytes shrink.
+    const char* dwk = getenv("NERFAIL_DW_KERNEL");
+    const bool use_lds = dwk != nullptr && dwk[0] == 'l';
+    if (bf16x3 && NT == 8 && use_lds) {   // LDS-staged kernel: one group per layer-part, in descriptor order
+        LArgs la;
+        la.acts = acts; la.dz = dz; la.ntiles = a.ntiles; la.a_slots = a.a_slots; la.z_slots = a.z_slots;
+        for (int di = 0; di < nd; ++di) la.desc[di] = a.desc[di];
+        int ng = 0;
+        la.cum[0] = 0;
+        for (int di = 0; di < nd; ++di)
+            for (int p = 0; p < a.desc[di].nparts; ++p) {
+                const LinDesc& d = a.desc[di];
+                const int LA = d.dz_tiles, LB = d.parts[p].ntiles;
+                int shape, ma, nb;
+                if (LA == 8 && LB == 8) { shape = 0; ma = 4; nb = 4; }
+                else if (LA == 4 && LB == 8) { shape = 1; ma = 4; nb = 2; }
+                else if (LA == 8 && LB == 2) { shape = 2; ma = 2; nb = 2; }
+                else if (LA == 4 && LB == 1) { shape = 3; ma = 1; nb = 1; }
+                else if (LA == 1 && LB == 4) { shape = 4; ma = 1; nb = 1; }
+                else if (LA == 1 && LB == 8) { shape = 5; ma = 1; nb = 2; }
+                else { set_error("nerfail_mlp_bwd_weights_bf16x3: unexpected layer shape"); return NERFAIL_EINVAL; }
+                NF_REQUIRE(ng < kMaxLGroups, "too many weight-gradient groups");
+                LGroup& g = la.grp[ng];
+                g.desc = di; g.part = p; g.dz_slot0 = d.dz_slot0; g.x_slot0 = d.parts[p].slot0; g.shape = shape;
+                const int G = (2 * (LA + LB) + 3) / 4;
+                la.cost[ng] = 96 * ma * nb + 70 * G + 150;          // cycles per k16-step: 3 MFMAs x 32 per tile pair + staging
+                la.cum[ng + 1] = la.cum[ng] + (long)la.cost[ng] * la.ntiles;
+                ++ng;
+            }
+        la.ngroups = ng;
+        long wgs = cu_count();
+        const long min_units = 2246L * 4;                          // at least ~4 full-layer tiles per workgroup
+        if (wgs > la.cum[ng] / min_units) wgs = la.cum[ng] / min_units > 0 ? la.cum[ng] / min_units : 1;
+        nerf_mlp_bwd_weights_lds_kernel<<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(la);
+        NF_LAUNCHED("nerf_mlp_bwd_weights_lds_kernel");
+        return NERFAIL_OK;
+    }
     int nt = 0;
     for (int di = 0; di < nd; ++di) {
         const LinDesc& d = a.desc[di];

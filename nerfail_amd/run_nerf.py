@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .optim import Adam, decayed_lrate  # noqa: F401
 from .run_nerf_helpers import (NeRF, Embedder, get_embedder, get_rays, get_rays_np, img2mse, mse2psnr, to8b,  # noqa: F401
                                sample_pdf, linspace01, _cuda, _k4, _c2w12)
 
@@ -177,7 +178,7 @@ def create_nerf(args):
                           skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(dev)
         grad_vars += list(model_fine.parameters())
     network_query_fn = FusedNetworkQuery(embed_fn, embeddirs_fn, args.netchunk)
-    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    optimizer = Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))      # RN:207; one fused kernel per step
     start = 0
     basedir, expname = args.basedir, args.expname
     if getattr(args, 'ft_path', None) is not None and args.ft_path != 'None':

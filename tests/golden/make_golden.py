@@ -477,8 +477,44 @@ def g12():
     save('g12_deepfool', **out)
 
 
+def g13():
+    """Optimizer of the training loop exactly as the reference builds and drives it: torch.optim.Adam(params, lr=lrate,
+    betas=(0.9, 0.999)) (RN:207), step() (RN:792), then the exponential lr decay written into param_groups
+    (RN:796-800; lrate_decay=500 in configs/lego.txt, 250 by default). CPU tensors => torch's single-tensor path."""
+    rs = np.random.RandomState(13)
+    shapes = [(8, 319), (256,), (3, 128), (1,)]
+    p0 = [rs.normal(scale=0.05, size=sh).astype(np.float32) for sh in shapes]
+    params = [torch.nn.Parameter(T(a.copy())) for a in p0]
+    lrate, lrate_decay = 5e-4, 250
+    optimizer = torch.optim.Adam(params=params, lr=lrate, betas=(0.9, 0.999))
+    out = {'n_tensors': len(shapes), 'n_steps': 6, 'lrate': lrate, 'lrate_decay': lrate_decay}
+    for i, a in enumerate(p0):
+        out['init_%d' % i] = a
+    global_step = 0
+    for it in range(6):
+        scale = [1e-3, 1.0, 1e-6, 30.0, 1e-2, 0.0][it]            # gradient magnitudes over 9 orders, then an all-zero step
+        for i, p in enumerate(params):
+            g = (rs.normal(size=p.shape) * scale).astype(np.float32)
+            out['g%d_%d' % (it, i)] = g
+            p.grad = T(g)
+        out['lr_%d' % it] = float(optimizer.param_groups[0]['lr'])
+        optimizer.step()
+        decay_rate = 0.1
+        decay_steps = lrate_decay * 1000
+        new_lrate = lrate * (decay_rate ** (global_step / decay_steps))      # RN:796-798
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = new_lrate
+        global_step += 100000 if it == 2 else 1                               # one large jump so the decay is visible
+        for i, p in enumerate(params):
+            st = optimizer.state[p]
+            out['p%d_%d' % (it, i)] = p.detach().numpy().copy()
+            out['m%d_%d' % (it, i)] = st['exp_avg'].numpy().copy()
+            out['v%d_%d' % (it, i)] = st['exp_avg_sq'].numpy().copy()
+    save('g13_adam', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
     for w in which:
         globals()[w]()
 

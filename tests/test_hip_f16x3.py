@@ -106,7 +106,8 @@ def test_f16x3_training_forward_gradients(golden, tag, D, W):
                 assert abs(np.linalg.norm(got.astype(np.float64)) - refn) < 5e-3 * refn, (nm, k)
 
 
-def test_split_backward_kernels_match_f32_kernels():
+@pytest.mark.parametrize('dw_kernel', ['reg', 'lds'])
+def test_split_backward_kernels_match_f32_kernels(dw_kernel, monkeypatch):
     """Backward-data (f16x3) and weight-gradient (bf16x3) kernels against the exact-f32 kernels on the SAME saved
     activations (same ReLU masks, so no discrete differences): every parameter gradient of a D=8 W=256 network agrees
     to 2e-5 L2 (measured: 1e-6 backward-data, 5e-6 weight gradients) although the upstream gradient spans ~8 orders
@@ -114,6 +115,7 @@ def test_split_backward_kernels_match_f32_kernels():
     two orders of magnitude at the first layers (the fp16 lo halves go subnormal)."""
     from conftest import l2_err
     from hiputil import hip_mlp_grads
+    monkeypatch.setenv('NERFAIL_DW_KERNEL', dw_kernel)     # register-fed (default) / LDS-staged bf16x3 weight-gradient kernel
     rng = np.random.default_rng(11)
     R, n = 128, 64
     pts = T(rng.uniform(-1.5, 1.5, (R, n, 3)).astype(np.float32))

@@ -83,7 +83,8 @@ def test_training_loop_adam_reduces_loss():
     from nerfail_amd import run_nerf as RN
     _, coarse = hip_nerf(4, 64, 41, requires_grad=True)
     _, fine = hip_nerf(4, 64, 42, requires_grad=True)
-    opt = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    from nerfail_amd.optim import Adam
+    opt = Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
     rays = T(synth.ray_batch(256, seed=7))
     target = T(np.random.RandomState(0).uniform(size=(256, 3)).astype(np.float32))
     gen = torch.Generator(device=dev()).manual_seed(0)

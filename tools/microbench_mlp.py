@@ -39,8 +39,17 @@ def timeit(fn, reps=10):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--lib', default=None, help='alternative libnerfail_hip build (tools/ablate_dw.py)')
+    ap.add_argument('--only', default=None, help='comma-separated kernel names')
+    ap.add_argument('--sizes', default='1024x64,1024x192,8192x192')
+    args = ap.parse_args()
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
+    only = set(args.only.split(',')) if args.only else None
     m = net(1)
-    for R, N in ((1024, 64), (1024, 192), (8192, 192)):
+    for R, N in [tuple(int(v) for v in sz.split('x')) for sz in args.sizes.split(',')]:
         M = R * N
         pts = torch.randn((R, N, 3), device=dev)
         vd = torch.nn.functional.normalize(torch.randn((R, 3), device=dev), dim=-1)
@@ -84,6 +93,8 @@ def main():
                                                           _train._grads_struct(m, grads), _lib.stream()))
         for name, fn in (('fwd_infer', f_inf), ('fwd_f16x3', f_f16), ('fwd_train', f_train), ('fwd_train_f16', f_train16),
                          ('bwd_data_f16', f_bd16), ('bwd_w_bf16x3', f_bw16), ('bwd_data', f_bd), ('bwd_weights', f_bw)):
+            if only and name not in only:
+                continue
             med, mn = timeit(fn)
             print('M=%7d %-12s median %8.3f ms  min %8.3f ms  -> %6.1f TFLOP/s (fwd-equivalent FLOPs)' %
                   (M, name, med, mn, M * FLOP / (med * 1e-3) / 1e12), flush=True)

@@ -17,7 +17,8 @@ def net(seed):
     return m.to(dev)
 coarse, fine = net(31), net(32)
 params = list(coarse.parameters()) + list(fine.parameters())
-opt = torch.optim.Adam(params, lr=5e-4)
+from nerfail_amd.optim import Adam
+opt = Adam(params, lr=5e-4)
 rays = torch.from_numpy(synth.ray_batch(1024, seed=1)).to(dev)
 target = torch.rand((1024, 3), device=dev)
 def sync(): torch.cuda.synchronize(); return time.perf_counter()
