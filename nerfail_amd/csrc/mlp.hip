@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
         f32x16 act[NT], acc[NT];
         float* __restrict__ A = nullptr;     // this tile's activation slots (training)
         if (TRAIN) {
-            A = a.acts + (size_t)tile * ((3 + (L.D + 1) * NT + NT / 2) * 1024);
+            A = a.acts + (size_t)tile * (train_a_slots(L.D, NT) * 1024);
             store_enc<10, 4 * kEmbQuads>(A, emb, lane);              // E0 E1: 63 channels
             store_enc<4, 4 * kDirQuads>(A + 2 * 1024, demb, lane);   // V: 27 channels
         }
@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
         load_bias<NT>(acc, P + L.b_off[0], h);
         mfma_scalars<NT, kEmbQuads>(acc, P + L.w_off[0], lane, emb);
         relu_to<NT>(act, acc, true);
-        if (TRAIN) store_tiles<NT>(A + 3 * 1024, act, lane);
+        if (TRAIN) {
+            store_tiles<NT>(A + 3 * 1024, act, lane);
+            store_mask<NT>(A + train_mask_slot0(L.D, NT) * 1024, 0, mask_of<NT>(act), lane);
+        }
 
         // ---- layers 1..D-1 (pts_linears, ReLU) and D (feature_linear, no activation)
         float alpha = 0.f;
@@ -244,7 +247,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
             }
             mfma_acts<NT, NT>(acc, w, lane, act);
             relu_to<NT>(act, acc, l < L.D);
-            if (TRAIN) store_tiles<NT>(A + (3 + l * NT) * 1024, act, lane);   // H_{l+1} for l < D, F for l == D
+            if (TRAIN) {
+                store_tiles<NT>(A + (3 + l * NT) * 1024, act, lane);   // H_{l+1} for l < D, F for l == D
+                if (l < L.D) store_mask<NT>(A + train_mask_slot0(L.D, NT) * 1024, l, mask_of<NT>(act), lane);
+            }
         }
 
         // ---- views_linears[0]: cat([feature, embedded dirs]) -> W/2, ReLU (RH:112-116)
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
             f32x16 hvr[OTV];
             relu_to<OTV>(hvr, hv, true);
             store_tiles<OTV>(A + (3 + (L.D + 1) * NT) * 1024, hvr, lane);
+            store_mask<OTV>(A + train_mask_slot0(L.D, NT) * 1024, L.D, mask_of<OTV>(hvr), lane);
         }
 
         // ---- rgb_linear: W/2 -> 3 (RH:118)
@@ -382,7 +389,7 @@ extern "C" int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int s
 extern "C" size_t nerfail_mlp_train_acts_floats(int D, int W, int64_t M) {
     MlpLayout L;
     if (!make_layout(D, W, -1, L) || M < 0) return 0;
-    return (size_t)((M + 31) / 32) * make_train_layout(D, W).a_slots * 1024;
+    return (size_t)((M + 31) / 32) * make_train_layout(D, W).a_slots * 1024;   // activation tiles + ReLU bit masks
 }
 
 extern "C" int nerfail_mlp_fwd_train(const float* packed, int D, int W, int skip, const float* pts, const float* viewdirs,

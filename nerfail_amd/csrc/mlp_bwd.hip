@@ -86,14 +86,14 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_kernel(BwdArgs a) {
         f32x16 dzv[OTV];
         {
             const float* wr = P + L.rgb_off;
+            const TileMask<OTV> mhv = load_mask<OTV>(A + TL.a_MASK * 1024, L.D, lane);
 #pragma unroll
             for (int t = 0; t < OTV; ++t) {
-                const f32x16 hvt = load_tile(A + (TL.a_HV + t) * 1024, lane);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float g = wr[((0 * OTV + t) * 2 + h) * 16 + r] * dr.x + wr[((1 * OTV + t) * 2 + h) * 16 + r] * dr.y +
                                     wr[((2 * OTV + t) * 2 + h) * 16 + r] * dr.z;
-                    dzv[t][r] = hvt[r] > 0.f ? g : 0.f;
+                    dzv[t][r] = mask_apply<OTV>(mhv, t, r, g);
                 }
             }
             store_tiles<OTV>(Z + TL.z_ZV * 1024, dzv, lane);
@@ -119,12 +119,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_kernel(BwdArgs a) {
 #pragma unroll 1
         for (int i = L.D - 1; i >= 0; --i) {
             // dZ_i = d_h_{i+1} * [h_{i+1} > 0]
+            const TileMask<NT> mk = load_mask<NT>(A + TL.a_MASK * 1024, i, lane);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f32x16 ht = load_tile(A + (TL.a_H1 + i * NT + t) * 1024, lane);
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cur[t][r] = ht[r] > 0.f ? nxt[t][r] : 0.f;
-            }
+                for (int r = 0; r < 16; ++r) cur[t][r] = mask_apply<NT>(mk, t, r, nxt[t][r]);
             store_tiles<NT>(Z + (TL.z_Z0 + i * NT) * 1024, cur, lane);
             if (i == 0) break;
 #pragma unroll

@@ -347,13 +347,16 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
         float* __restrict__ A = nullptr;                             // this tile's activation slots (training)
         float* __restrict__ lpA = nullptr;                           // lane pointer for accumulator-layout stores
         if (TRAIN && save) {
-            A = a.acts + (size_t)tile * ((3 + (L.D + 1) * NT + NT / 2) * 1024);
+            A = a.acts + (size_t)tile * (train_a_slots(L.D, NT) * 1024);
             lpA = A + acc_lane_off(lane);
             store_enc<10, 32>(A, emb, lane);
             store_enc<4, 16>(A + 2 * 1024, demb, lane);
         }
         // acc (scaled by 2^10) -> next layer's B fragments; training also saves the fp32 activation (slot0 = first slot)
         auto to_operands = [&](bool relu, int slot0) {
+            TileMask<NT> mk;
+#pragma unroll
+            for (int i = 0; i < (NT + 1) / 2; ++i) mk.w[i] = 0u;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -366,10 +369,12 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
                         if (TRAIN && save) {
                             const int r = 8 * sgrp + q;
                             lpA[(slot0 + t) * 1024 + acc_reg_off(r)] = v[q];
+                            mk.w[t >> 1] |= (v[q] > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
                         }
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
                 }
+            if (TRAIN && save && relu) store_mask<NT>(A + train_mask_slot0(L.D, NT) * 1024, (slot0 - 3) / NT, mk, lane);
         };
 
         // ---- layer 0
@@ -413,11 +418,18 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
             else { hi = dhi[ks - 2 * NT]; lo = dlo[ks - 2 * NT]; }
         });
         if (TRAIN && save) {
+            TileMask<OTV> mk;
+#pragma unroll
+            for (int i = 0; i < (OTV + 1) / 2; ++i) mk.w[i] = 0u;
 #pragma unroll
             for (int t = 0; t < OTV; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    lpA[(3 + (L.D + 1) * NT + t) * 1024 + acc_reg_off(r)] = fmaxf(hv[t][r] * kWInv, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const float x = fmaxf(hv[t][r] * kWInv, 0.f);
+                    lpA[(3 + (L.D + 1) * NT + t) * 1024 + acc_reg_off(r)] = x;
+                    mk.w[t >> 1] |= (x > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+                }
+            store_mask<OTV>(A + train_mask_slot0(L.D, NT) * 1024, L.D, mk, lane);
         }
         // ---- rgb_linear on VALU (fp32)
         const float* wr = P + L.rgb_off;
@@ -542,9 +554,9 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
         // ---- rgb_linear backward (fp32 VALU): dZ_v = (W_rgb^T d_rgb) * [hv > 0]; operands of the views^T part
         {
             const float* wr = P + L.rgb_off;
+            const TileMask<OTV> mhv = load_mask<OTV>(A + TL.a_MASK * 1024, L.D, lane);
 #pragma unroll
             for (int t = 0; t < OTV; ++t) {
-                const f32x16 hvt = load_tile(A + (TL.a_HV + t) * 1024, lane);
 #pragma unroll
                 for (int sgrp = 0; sgrp < 2; ++sgrp) {
                     float v[8];
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
                         const int r = 8 * sgrp + q;
                         const float g = wr[((0 * OTV + t) * 2 + h) * 16 + r] * dr.x + wr[((1 * OTV + t) * 2 + h) * 16 + r] * dr.y +
                                         wr[((2 * OTV + t) * 2 + h) * 16 + r] * dr.z;
-                        const float dzv = hvt[r] > 0.f ? g : 0.f;
+                        const float dzv = mask_apply<OTV>(mhv, t, r, g);
                         if (live) lpZ[(TL.z_ZV + t) * 1024 + acc_reg_off(r)] = dzv;
                         v[q] = dzv * S;
                     }
@@ -567,16 +579,16 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         f16_part<NT, 1, 2 * OTV, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
         // acc = d_feature * S * 2^10: store dZ_F (unscaled), operands for feature^T
-        auto emit = [&](int slot0, const float* __restrict__ mask_base) {   // acc -> (masked) dZ: store unscaled, split rescaled
+        auto emit = [&](int slot0, int mask_entry) {   // acc -> (masked) dZ: store unscaled, split rescaled; mask_entry < 0: none
             float m = 0.f;
+            TileMask<NT> mk;
+            if (mask_entry >= 0) mk = load_mask<NT>(A + TL.a_MASK * 1024, mask_entry, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                f32x16 ht;
-                if (mask_base != nullptr) ht = load_tile(mask_base + t * 1024, lane);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float x = acc[t][r] * kWInv;                            // dZ * S
-                    if (mask_base != nullptr) x = ht[r] > 0.f ? x : 0.f;
+                    if (mask_entry >= 0) x = mask_apply<NT>(mk, t, r, x);
                     acc[t][r] = x;
                     m = fmaxf(m, fabsf(x));
                 }
@@ -604,7 +616,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
                 }
         };
-        emit(TL.z_ZF, nullptr);
+        emit(TL.z_ZF, -1);
         // ---- feature^T + alpha: d_h = Wf^T d_feature + w_alpha * d_sigma
         {
             const float* wa = P + L.alpha_off;
@@ -617,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
         // ---- pts_linears[D-1 .. 0]
 #pragma unroll 1
         for (int i = L.D - 1; i >= 0; --i) {
-            emit(TL.z_Z0 + i * NT, A + (TL.a_H1 + i * NT) * 1024);       // dZ_i = d_h_{i+1} * [h_{i+1} > 0]
+            emit(TL.z_Z0 + i * NT, i);                                    // dZ_i = d_h_{i+1} * [h_{i+1} > 0]
             if (i == 0) break;
 #pragma unroll
             for (int t = 0; t < NT; ++t)

@@ -67,15 +67,19 @@ static bool make_layout(int D, int W, int skip, MlpLayout& L) {
 //               outputs of pts_linears), F (NT, feature_linear output), HV (NT/2, post-ReLU views output)
 //   dz   slots: Z_0..Z_{D-1} (NT each, gradient w.r.t. the pre-activation of pts_linears[i]), ZF (NT), ZV (NT/2),
 //               ZR (1: d_raw, channels 0..3 = rgb, sigma)
+__host__ __device__ inline int train_mask_slots(int D) { return (D + 1 + 3) / 4; }      // (D+1) entries of 1 KB
+__host__ __device__ inline int train_mask_slot0(int D, int NT) { return 3 + (D + 1) * NT + NT / 2; }
+__host__ __device__ inline int train_a_slots(int D, int NT) { return train_mask_slot0(D, NT) + train_mask_slots(D); }
+
 struct TrainLayout {
     int NT, D, OTV;
-    int a_slots, a_E, a_V, a_H1, a_F, a_HV;
+    int a_slots, a_E, a_V, a_H1, a_F, a_HV, a_MASK;
     int z_slots, z_Z0, z_ZF, z_ZV, z_ZR;
 };
 static inline TrainLayout make_train_layout(int D, int W) {
     TrainLayout t;
     t.NT = W / 32; t.D = D; t.OTV = t.NT / 2;
-    t.a_E = 0; t.a_V = 2; t.a_H1 = 3; t.a_F = 3 + D * t.NT; t.a_HV = t.a_F + t.NT; t.a_slots = t.a_HV + t.OTV;
+    t.a_E = 0; t.a_V = 2; t.a_H1 = 3; t.a_F = 3 + D * t.NT; t.a_HV = t.a_F + t.NT; t.a_MASK = t.a_HV + t.OTV; t.a_slots = t.a_MASK + train_mask_slots(D);
     t.z_Z0 = 0; t.z_ZF = D * t.NT; t.z_ZV = t.z_ZF + t.NT; t.z_ZR = t.z_ZV + t.OTV; t.z_slots = t.z_ZR + 1;
     return t;
 }
@@ -193,6 +197,54 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int 
     for (int r = 0; r < 16; ++r) v[r] = lp[acc_reg_off(r)];
     return v;
 }
+// ReLU masks. The backward-data pass needs only the SIGN of every saved activation; reading the fp32 tiles for it
+// doubled that kernel's HBM reads. The forward therefore also writes one bit per activation: entry e of a tile
+// (e = 0..D-1 for H_{e+1}, e = D for HV; 1 KB each, in the a_MASK slots) is [64 lanes][4 dwords]; dword w of a lane
+// holds its accumulator tiles 2w (bits 0-15) and 2w+1 (bits 16-31), bit r = (register r > 0).
+template <int NTILES>
+struct TileMask { unsigned w[(NTILES + 1) / 2]; };
+
+template <int NTILES>
+__device__ __forceinline__ TileMask<NTILES> mask_of(const f32x16 (&a)[NTILES]) {
+    TileMask<NTILES> m;
+#pragma unroll
+    for (int i = 0; i < (NTILES + 1) / 2; ++i) m.w[i] = 0u;
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m.w[t >> 1] |= (a[t][r] > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+    return m;
+}
+template <int NTILES>
+__device__ __forceinline__ void store_mask(float* __restrict__ mask_slots, int entry, const TileMask<NTILES>& m, int lane) {
+    unsigned* __restrict__ q = reinterpret_cast<unsigned*>(mask_slots) + entry * 256 + lane * 4;
+    if constexpr (NTILES == 8) {
+        *reinterpret_cast<uint4*>(q) = make_uint4(m.w[0], m.w[1], m.w[2], m.w[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < (NTILES + 1) / 2; ++i) q[i] = m.w[i];
+    }
+}
+template <int NTILES>
+__device__ __forceinline__ TileMask<NTILES> load_mask(const float* __restrict__ mask_slots, int entry, int lane) {
+    const unsigned* __restrict__ q = reinterpret_cast<const unsigned*>(mask_slots) + entry * 256 + lane * 4;
+    TileMask<NTILES> m;
+    if constexpr (NTILES == 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(q);
+        m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < (NTILES + 1) / 2; ++i) m.w[i] = q[i];
+    }
+    return m;
+}
+// x where the activation of (tile t, register r) was positive, else +0: one v_bfe_i32 (0 / all ones) + one v_and
+template <int NTILES>
+__device__ __forceinline__ float mask_apply(const TileMask<NTILES>& m, int t, int r, float x) {
+    const int k = __builtin_amdgcn_sbfe((int)m.w[t >> 1], 16 * (t & 1) + r, 1);
+    return __uint_as_float(__float_as_uint(x) & (unsigned)k);
+}
+
 // positional-encoding k-step values (per lane: step s -> channel enc_channel(s, h)) <-> channel-major slots.
 // BANDS = 10 (pts: 63 channels in 2 slots) or 4 (dirs: 27 channels in 1 slot); padding channels are zero-filled so
 // the weight-gradient kernel never reads uninitialised memory. Channel c of an encoding lives in slot c / 32.
