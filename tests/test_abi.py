@@ -42,7 +42,15 @@ def test_argument_validation_without_gpu():
         _lib.check(lib.nerfail_gauss_weight(None, 1, 1, -1.0, None, None))
     # sizing helpers are pure host functions
     assert lib.nerfail_mlp_packed_T_floats(8, 256, 4) == 9 * 32 * 8 * 256 - 16 * 8 * 256    # 8 full layers + views (half the quads)
-    assert lib.nerfail_mlp_train_acts_floats(8, 256, 64) == 2 * (3 + 9 * 8 + 4) * 1024
+    # per 32-sample tile: E0 E1 V + 8 layers and feature x 8 slots + 4 hv slots + 3 slots of ReLU bit masks
+    assert lib.nerfail_mlp_train_acts_floats(8, 256, 64) == 2 * (3 + 9 * 8 + 4 + 3) * 1024
+    # optimizer step: nothing to do / NULL table / NULL tensor pointers are rejected before any launch
+    assert lib.nerfail_adam_step(None, 0, 0.9, 0.999, 1e-8, None) == 0
+    assert lib.nerfail_adam_step(None, 2, 0.9, 0.999, 1e-8, None) == 1
+    bad = _lib.AdamTensor()
+    bad.numel, bad.bias_correction2_sqrt = 8, 1.0
+    assert lib.nerfail_adam_step((_lib.AdamTensor * 1)(bad), 1, 0.9, 0.999, 1e-8, None) == 1
+    assert lib.nerfail_adam_step((_lib.AdamTensor * 1)(bad), 1, 1.5, 0.999, 1e-8, None) == 1
     assert lib.nerfail_mlp_train_dz_floats(8, 256, 33) == 2 * (8 * 8 + 8 + 4 + 1) * 1024
     assert lib.nerfail_mlp_train_acts_floats(8, 100, 64) == 0
     assert lib.nerfail_knn8_grid_workspace_bytes(7) == 0 and lib.nerfail_knn8_grid_workspace_bytes(1 << 24) == 0
