@@ -239,6 +239,15 @@ int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* gra
                           int64_t P, float epsilon, float* pixel_grad_scratch, int accumulate, float* grad_spatial,
                           void* stream);
 
+/* The same backward for n_rhs (1..8) upstream gradients at once - the class-logit gradients of one DeepFool iteration
+ * (deepfool.py:66-96 takes them one autograd.grad call at a time). grad_x_rgba: [n_rhs][B*P,4]; grad_spatial:
+ * [n_rhs][Ns,4], overwritten; pixel_grad_scratch: n_rhs*B*P*4 floats. Row sums run in the same order as
+ * nerfail_gauss_bwd_csr, so each right-hand side gets bitwise the result of a single call. */
+int nerfail_gauss_bwd_csr_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,
+                                const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns,
+                                int64_t B, int64_t P, float epsilon, float* pixel_grad_scratch, float* grad_spatial,
+                                void* stream);
+
 /* NeRFail-S sign step, AS:352-392: rgb <- rgb -/+ a*sign(grad) where alpha > 0 else 0, clamped to
  * init +- epsilon; alpha channel copied. spatial/grad/spatial_init/out are [n,4]; out may alias spatial. */
 int nerfail_igsm_step(const float* spatial, const float* grad, const float* spatial_init, int64_t n,

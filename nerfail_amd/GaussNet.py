@@ -162,6 +162,10 @@ class gauss_net(nn.Module):
 
     def forward(self, spatial_rgb, weight_and_index_list, ori_img, zero_init_mask: bool = False):
         ori_img = _lib.f32c(torch.as_tensor(ori_img), _cuda())           # GN:55
+        if not (isinstance(weight_and_index_list, torch.Tensor) and weight_and_index_list.is_cuda
+                and weight_and_index_list.dtype == torch.float32 and weight_and_index_list.is_contiguous()):
+            weight_and_index_list = _lib.f32c(weight_and_index_list, _cuda())
+        self._last_ori, self._last_wi = ori_img, weight_and_index_list   # for logit_gradients()
         x, x_rgba = gauss_gather(spatial_rgb, weight_and_index_list, ori_img, self.epsilon,
                                  self._mm() if self.update_epsilon_3d else None, self.deterministic)
         # ---- cold tail, GN:121-157 (stock PyTorch)
@@ -181,6 +185,43 @@ class gauss_net(nn.Module):
         cla = self.model(cla_x_3channel)
         ori_cla = self.model(cla_ori_img_3channel)
         return x, x_rgba, cla, ori_img, ori_cla
+
+
+    # ---- all class-logit gradients of one forward in ONE pass over the inverted index (DeepFool)
+    def logit_gradients(self, spatial_rgb, weight_and_index_list, x, x_rgba, cla, classes):
+        """d cla[0, k] / d spatial_rgb for every k in `classes` (<= 8): tensor [len(classes), *spatial_rgb.shape].
+
+        `x, x_rgba, cla` are what forward() just returned for this spatial_rgb (graph still alive). The classifier is
+        differentiated down to x_rgba by stock PyTorch (one backward per class); the pixel<->3-D map - the part the reference pays len(classes) scatter passes for - is one
+        nerfail_gauss_bwd_csr_multi launch. Each slice is bitwise what autograd through forward() returns."""
+        if cla.shape[0] != 1:
+            raise ValueError('logit_gradients differentiates one view at a time (deepfool runs at batch 1, AN:82)')
+        classes = [int(k) for k in classes]
+        C = len(classes)
+        if not 1 <= C <= 8:
+            raise ValueError('1..8 classes per call')
+        sel = torch.zeros((C, 1, cla.shape[1]), dtype=cla.dtype, device=cla.device)
+        sel[torch.arange(C), 0, torch.tensor(classes)] = 1.0
+        # classifier part (stock PyTorch / MIOpen): one backward per class. A single batched backward
+        # (is_grads_batched=True) is available with self.batched_classifier_backward = True; on the 800x800 victim CNN
+        # it measured slower (8.9 vs 7.9 ms for 8 classes), so it is off by default.
+        if getattr(self, 'batched_classifier_backward', False):
+            J = torch.autograd.grad(cla, x_rgba, grad_outputs=sel, retain_graph=True, is_grads_batched=True)[0]
+        else:
+            J = torch.stack([torch.autograd.grad(cla, x_rgba, grad_outputs=sel[i], retain_graph=True)[0] for i in range(C)])
+        wi = weight_and_index_list
+        B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
+        n = spatial_rgb.numel() // 4
+        csr = csr_for(wi, n)
+        J = _lib.f32c(J).reshape(C, B * P, 4)
+        ori = _lib.f32c(self._last_ori)
+        out = torch.empty((C, n, 4), dtype=torch.float32, device=J.device)
+        scratch = torch.empty((C * B * P, 4), dtype=torch.float32, device=J.device)
+        eps = -1.0 if self.epsilon is None else float(self.epsilon)
+        _lib.check(_lib.load().nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(_lib.f32c(x)), _lib.dev(J), C,
+                                                           _lib.dev(csr.row_ptr), _lib.dev(csr.contrib), _lib.dev(csr.w_sorted),
+                                                           n, B, P, eps, _lib.dev(scratch), _lib.dev(out), _lib.stream()))
+        return out.reshape((C,) + tuple(spatial_rgb.shape))
 
 
 class create_gauss_w(nn.Module):

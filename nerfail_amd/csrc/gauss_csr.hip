@@ -153,6 +153,107 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __rest
     grad_spatial[j] = acc;
 }
 
+// ---- multi-RHS form (DeepFool: the gradients of all class logits of one iteration, deepfool.py:66-96). The index
+// arrays are walked ONCE for C right-hand sides; the per-pixel gradients are stored [pixel][C] so that the C float4 a
+// contribution needs are one contiguous run (C = 8: one 128-byte line) instead of C scattered 16-byte gathers.
+__global__ __launch_bounds__(256) void gauss_pixel_grad_multi_kernel(const float4* __restrict__ ori, const float4* __restrict__ x_saved,
+                                                                     const float4* __restrict__ grad_x_rgba, long n, int C,
+                                                                     float epsilon, float4* __restrict__ g_out) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (pixel, rhs) pairs, rhs fastest
+    if (g >= n * C) return;
+    const long pix = g / C;
+    const int c_ = (int)(g - pix * C);
+    const float4 x = x_saved[pix];
+    const float4 o = ori[pix];
+    float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o.w > 0.f) {
+        const float4 gr = grad_x_rgba[(long)c_ * n + pix];
+        const float alpha = x.w / 255.0f;
+        const float xc[3] = {x.x, x.y, x.z}, oc[3] = {o.x, o.y, o.z}, grc[3] = {gr.x, gr.y, gr.z};
+        float gxc[3] = {0.f, 0.f, 0.f};
+        float ga = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float d = xc[c] * alpha;
+            bool pass = true;
+            if (epsilon >= 0.f) {
+                pass = (d >= -epsilon) && (d <= epsilon);
+                d = fminf(fmaxf(d, -epsilon), epsilon);
+            }
+            const float pre = oc[c] + d;
+            pass = pass && (pre >= 0.f) && (pre <= 255.f);
+            const float gd = pass ? grc[c] : 0.f;
+            gxc[c] = gd * alpha;
+            ga += gd * xc[c];
+        }
+        gx.x += gxc[0]; gx.y += gxc[1]; gx.z += gxc[2];
+        gx.w += ga / 255.0f;
+    }
+    g_out[g] = gx;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void gauss_row_reduce_multi_kernel(const int* __restrict__ row_ptr, const int* __restrict__ contrib,
+                                                                     const float* __restrict__ w_sorted,
+                                                                     const float4* __restrict__ g_pix, long Ns,
+                                                                     float4* __restrict__ grad_spatial) {
+    __shared__ int s_id[4][kRowCap];
+    __shared__ float s_w[4][kRowCap];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long j0 = j - lane;
+    if (j0 >= Ns) return;
+    const long jc = j < Ns ? j : Ns - 1;
+    const int c0 = row_ptr[jc];
+    const int len = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
+    const int base = __shfl(c0, 0, 64);
+    const long jl = (j0 + 64 < Ns) ? j0 + 64 : Ns;
+    const int n = row_ptr[jl] - base;
+    int maxlen = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    float4 acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool staged = n <= kRowCap;
+    if (staged) {
+        for (int i = lane; i < n; i += 64) { s_id[wv][i] = contrib[base + i]; s_w[wv][i] = w_sorted[base + i]; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    const int r0 = c0 - base;
+    for (int k = 0; k < maxlen; k += 2) {          // same contribution order per row as the single-RHS kernel => same bits
+        int id[2];
+        float w[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool ok = k + u < len;
+            const int c = ok ? r0 + k + u : 0;
+            if (staged) { id[u] = s_id[wv][c]; w[u] = s_w[wv][c]; }
+            else { id[u] = contrib[base + c]; w[u] = w_sorted[base + c]; }
+            if (!ok) w[u] = 0.f;
+        }
+        float4 g[2][C];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> 3) * C + c];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (k + u < len) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    acc[c].x += w[u] * g[u][c].x; acc[c].y += w[u] * g[u][c].y;
+                    acc[c].z += w[u] * g[u][c].z; acc[c].w += w[u] * g[u][c].w;
+                }
+            }
+        }
+    }
+    if (j >= Ns) return;
+#pragma unroll
+    for (int c = 0; c < C; ++c) grad_spatial[(long)c * Ns + j] = acc[c];
+}
+
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t cub_temp_bytes(long n) {
@@ -219,5 +320,35 @@ extern "C" int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const
     gauss_row_reduce_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(
         row_ptr, contrib, w_sorted, (const float4*)pixel_grad_scratch, Ns, accumulate, (float4*)grad_spatial);
     NF_LAUNCHED("gauss_row_reduce_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_gauss_bwd_csr_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,
+                                           const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns,
+                                           int64_t B, int64_t P, float epsilon, float* pixel_grad_scratch,
+                                           float* grad_spatial, void* stream) {
+    NF_REQUIRE(Ns > 0 && B > 0 && P > 0, "bad sizes");
+    NF_REQUIRE(n_rhs >= 1 && n_rhs <= 8, "n_rhs must be in 1..8");
+    NF_REQUIRE(ori_img && x && grad_x_rgba && row_ptr && contrib && w_sorted && pixel_grad_scratch && grad_spatial, "NULL pointer");
+    hipStream_t s = as_stream(stream);
+    const long n = B * P;
+    const long total = n * n_rhs;
+    gauss_pixel_grad_multi_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x_rgba, n, n_rhs, epsilon, (float4*)pixel_grad_scratch);
+    NF_LAUNCHED("gauss_pixel_grad_multi_kernel");
+    const dim3 grid((unsigned)((Ns + 255) / 256)), block(256);
+#define NF_ROWS(C) gauss_row_reduce_multi_kernel<C><<<grid, block, 0, s>>>(row_ptr, contrib, w_sorted, (const float4*)pixel_grad_scratch, Ns, (float4*)grad_spatial)
+    switch (n_rhs) {
+        case 1: NF_ROWS(1); break;
+        case 2: NF_ROWS(2); break;
+        case 3: NF_ROWS(3); break;
+        case 4: NF_ROWS(4); break;
+        case 5: NF_ROWS(5); break;
+        case 6: NF_ROWS(6); break;
+        case 7: NF_ROWS(7); break;
+        default: NF_ROWS(8); break;
+    }
+#undef NF_ROWS
+    NF_LAUNCHED("gauss_row_reduce_multi_kernel");
     return NERFAIL_OK;
 }

@@ -4,9 +4,12 @@ spatial_rgb).
 
 The control flow (margins m1 / m2, per-class minimal step, accumulation, clamp, alpha restore) is host logic and
 stays Python, as SURVEY.md section 2 #10 scopes it; every forward / backward through the pixel<->3-D map runs in the
-HIP kernels behind `net` (gauss_net: K10 forward, K11 backward). One saving over the reference that cannot change the
-result: the gradient of the original class logit is computed once per iteration instead of once per competing class
-(the reference recomputes the identical tensor up to 7 times at deepfool.py:76-77).
+HIP kernels behind `net` (gauss_net: K10 forward, K11 backward). Two savings over the reference that cannot change
+the result: the gradient of the original class logit is computed once per iteration instead of once per competing
+class (the reference recomputes the identical tensor up to 7 times at deepfool.py:76-77), and when `net` is
+nerfail_amd's gauss_net all class gradients of an iteration come from ONE multi-right-hand-side pass over the
+inverted index (gauss_net.logit_gradients -> nerfail_gauss_bwd_csr_multi) instead of one autograd.grad call each; the
+competing class is then chosen on the device (first minimum, NaN never chosen: deepfool.py:85's strict `<`).
 """
 import torch
 
@@ -31,7 +34,7 @@ def deepfool(net_input, e, net, num_classes=8, max_iter=20, target_label: int = 
     loop_i = 0
     while loop_i < max_iter:
         spatial_rgb = spatial_rgb.detach().clone().requires_grad_(True)
-        _, _, cla, _, ori_cla = net(spatial_rgb, weight_and_index, ori_img)             # deepfool.py:51
+        x_out, x_rgba, cla, _, ori_cla = net(spatial_rgb, weight_and_index, ori_img)     # deepfool.py:51
         ori_cla_max_index = torch.max(ori_cla, 1)[1]
         o = int(ori_cla_max_index)
         bump = torch.zeros_like(cla)                                                    # deepfool.py:53-57 (+m1), out of place
@@ -47,25 +50,28 @@ def deepfool(net_input, e, net, num_classes=8, max_iter=20, target_label: int = 
         if (target_label is not None) and int(cla_max_index) == int(target_label):
             break
 
-        grad_o = _grad(cla[:, o].sum(), spatial_rgb)
+        multi = hasattr(net, 'logit_gradients') and getattr(net, 'deterministic', False) and num_classes <= 8
         if target_label is None:
-            min_value = float('inf')
-            dr = torch.zeros_like(rot)
-            for k in range(num_classes):
-                if k == o:
-                    continue
-                grad_prime = _grad(cla[:, k].sum(), spatial_rgb) - grad_o
-                f_prime = (cla[:, k] - (cla[:, o] + m2)).detach()
-                nrm = torch.norm(grad_prime)
-                value_r = float(torch.abs(f_prime) / (nrm + 0.0001))
-                if value_r < min_value:
-                    dr = (torch.abs(f_prime) / ((nrm ** 2) + 0.0001)) * grad_prime
-                    min_value = value_r
+            ks = [k for k in range(num_classes) if k != o]
         else:
-            k = int(target_label)
-            grad_prime = _grad(cla[:, k].sum(), spatial_rgb) - grad_o
-            f_prime = (cla[:, k] - (cla[:, o] + m2)).detach()
-            dr = (torch.abs(f_prime) / ((torch.norm(grad_prime) ** 2) + 0.0001)) * grad_prime
+            ks = [int(target_label)]
+        if multi:
+            G = net.logit_gradients(spatial_rgb, net._last_wi, x_out, x_rgba, cla, [o] + ks)
+            grad_o, grads_k = G[0], G[1:]
+        else:
+            grad_o = _grad(cla[:, o].sum(), spatial_rgb)
+            grads_k = torch.stack([_grad(cla[:, k].sum(), spatial_rgb) for k in ks])
+        grad_prime = grads_k - grad_o.unsqueeze(0)                                      # deepfool.py:78 for every k
+        f_prime = (cla[0, ks] - (cla[0, o] + m2)).detach()                              # deepfool.py:79
+        nrm = torch.linalg.vector_norm(grad_prime.reshape(len(ks), -1), dim=1)          # torch.norm(grad_prime)
+        if target_label is None:
+            value_r = torch.abs(f_prime) / (nrm + 0.0001)                               # deepfool.py:81
+            value_r = torch.where(torch.isnan(value_r), torch.full_like(value_r, float('inf')), value_r)
+            best = torch.argmin(value_r)                                                # first minimum = strict `<` scan
+            scale = torch.abs(f_prime[best]) / ((nrm[best] ** 2) + 0.0001)              # deepfool.py:86
+            dr = torch.where(torch.isinf(value_r[best]), torch.zeros_like(grad_prime[0]), scale * grad_prime[best])
+        else:
+            dr = (torch.abs(f_prime[0]) / ((nrm[0] ** 2) + 0.0001)) * grad_prime[0]      # deepfool.py:92-96
 
         rot = (rot + dr).detach()
         spatial_rgb = torch.clamp((spatial_rgb_0 + (overshoot * rot)).detach(), -255, 255)

@@ -29,3 +29,63 @@ def test_deepfool_matches_reference(golden, tag, target, over, iters):
     assert rel_err(N(rot), g[tag + '_rot']) < 1e-3            # 6-12 chained gradient steps in fp32
     assert rel_err(N(s_new), g[tag + '_s_new']) < 1e-3
     assert np.array_equal(N(s_new)[..., 3], g['s'][..., 3])   # alpha channel untouched
+
+
+def _small_problem(seed=5, P=3, H=24, W=20, eps=None):
+    import synth
+    from nerfail_amd.GaussNet import create_gauss_w
+    rs = np.random.RandomState(seed)
+    s = rs.uniform(-40, 40, size=(P, H, W, 4)).astype(np.float32)
+    s[..., 3] = rs.choice([0.0, 128.0, 255.0], size=(P, H, W))
+    ori = synth.disc_alpha_image(1, H, W, seed=seed + 1)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(1, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, size=(1, H, W, 8)).astype(np.float32)
+    wi, _ = create_gauss_w(dev(), 0.02)(T(np.stack([dist, idx], 1)))
+    return T(s), wi, T(ori)
+
+
+@pytest.mark.parametrize('eps', [None, 12.0])
+def test_multi_rhs_backward_is_bitwise_the_single_backward(eps):
+    """nerfail_gauss_bwd_csr_multi (all class gradients in one pass over the inverted index) vs one
+    nerfail_gauss_bwd_csr call per right-hand side: identical bits, for 1..8 right-hand sides."""
+    from nerfail_amd import _lib
+    from nerfail_amd.GaussNet import gauss_gather, csr_for
+    s, wi, ori = _small_problem(eps=eps)
+    lib = _lib.load()
+    st = s.clone().requires_grad_(True)
+    x, x_rgba = gauss_gather(st, wi, ori, eps, None, True)
+    n, B, P = s.numel() // 4, 1, ori.shape[1] * ori.shape[2]
+    csr = csr_for(wi, n)
+    rng = np.random.default_rng(0)
+    for C in (1, 3, 8):
+        J = T(rng.normal(size=(C, B * P, 4)).astype(np.float32))
+        out = torch.empty((C, n, 4), device=dev())
+        scratch = torch.empty((C * B * P, 4), device=dev())
+        _lib.check(lib.nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(x.detach()), _lib.dev(J), C, _lib.dev(csr.row_ptr),
+                                                   _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), n, B, P,
+                                                   -1.0 if eps is None else eps, _lib.dev(scratch), _lib.dev(out), _lib.stream()))
+        for c in range(C):
+            ref = torch.autograd.grad(x_rgba, st, grad_outputs=J[c].reshape(x_rgba.shape), retain_graph=True)[0]
+            assert torch.equal(out[c].reshape(ref.shape), ref), (C, c)
+    assert lib.nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(x.detach()), _lib.dev(J), 9, _lib.dev(csr.row_ptr),
+                                           _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), n, B, P, -1.0, _lib.dev(scratch),
+                                           _lib.dev(out), _lib.stream()) != 0
+
+
+def test_logit_gradients_match_autograd():
+    """gauss_net.logit_gradients (batched classifier backward + multi-RHS K11) vs torch.autograd.grad through forward(),
+    one class at a time, with a small CNN (conv / ReLU / max-pool: the op set of the reference's classifier)."""
+    from nerfail_amd.GaussNet import gauss_net
+    s, wi, ori = _small_problem(seed=9)
+    torch.manual_seed(3)
+    cnn = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.ReLU(), torch.nn.MaxPool2d(2), torch.nn.Flatten(),
+                              torch.nn.Linear(8 * 11 * 9, 8)).to(dev())
+    cnn.requires_grad_(False)
+    net = gauss_net(dev(), 0.02, cnn, 'my_model', epsilon=None)
+    st = s.clone().requires_grad_(True)
+    x, x_rgba, cla, _, _ = net(st, wi, ori)
+    classes = [5, 0, 1, 2, 3, 4, 6, 7]
+    G = net.logit_gradients(st, wi, x, x_rgba, cla, classes)
+    for i, k in enumerate(classes):
+        ref = torch.autograd.grad(cla[0, k], st, retain_graph=True)[0]
+        assert rel_err(N(G[i]), N(ref)) < 1e-6, k
