@@ -36,7 +36,7 @@ def _args(basedir):
 def test_pipeline_through_files(tmp_path):
     from nerfail_amd import nerf_to_coord as NC
     from nerfail_amd.create_index_and_dist import create_index_and_dist
-    from nerfail_amd.GaussNet import create_gauss_w, gauss_net
+    from nerfail_amd.GaussNet import gauss_net
     from nerfail_amd.attack import nerfail_s_step
     base = str(tmp_path)
     logs = os.path.join(base, 'logs')
@@ -91,12 +91,19 @@ def test_pipeline_through_files(tmp_path):
     assert float(own[0][..., 0].max()) == 0.0
     assert np.array_equal(own[1][..., 0].numpy().reshape(-1), H * W * 1 + np.arange(H * W, dtype=np.float32))
 
-    # ---- dist -> weight (DW:82-97), batch of the 4 test views
+    # ---- dist -> weight driver (DW:82-97) over all splits, then the batch of the 4 test views as the attack loads it
+    from nerfail_amd.dist_to_weight import dist_to_weight
+    v = dist_to_weight('toy', basedir=base, test_number=4, val_number=2, train_number=2, c=0.02)
     dai = torch.stack([torch.load(os.path.join(exp, 'index_and_dist', 'test', '%d.pth' % i)) for i in range(4)])
-    wi, dist_ = create_gauss_w(dev(), 0.02)(dai)
+    files = torch.stack([torch.load(os.path.join(exp, 'index_and_weight', 'test', '%d.pth' % i)) for i in range(4)])
+    assert tuple(files.shape) == (4, 2, H, W, 8) and files.dtype == torch.float32 and not files.is_cuda
     want, _ = OG.create_gauss_w(dai.numpy(), 0.02)
-    assert rel_err(N(wi)[:, 0], want[:, 0]) < 1e-6
-    assert np.array_equal(N(wi)[:, 1], dai.numpy()[:, 1])
+    assert rel_err(files.numpy()[:, 0], want[:, 0]) < 1e-6
+    assert np.array_equal(files.numpy()[:, 1], dai.numpy()[:, 1])
+    all_d = [torch.load(os.path.join(exp, 'index_and_dist', sp, '%d.pth' % i))[0] for sp, n in (('test', 4), ('val', 2), ('train', 2))
+             for i in range(n)]
+    assert abs(v - float(np.mean([float((d.double() ** 2).mean()) for d in all_d]))) < 1e-6 * max(v, 1e-12) + 1e-12
+    wi = files.to(dev())
 
     # ---- two NeRFail-S steps over these maps with a toy victim
     torch.manual_seed(0)
