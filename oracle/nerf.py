@@ -173,8 +173,10 @@ def coarse_z_vals(near, far, N_samples, t_rand=None, lindisp=False):
 
 
 def render_rays(ray_batch, sd_coarse, N_samples, N_importance=0, sd_fine=None, white_bkgd=False,
-                t_rand=None, u=None, D=8, W=256, lindisp=False, want_pts_max=True, return_weights=False):
-    """RN:308-418 (+ NC:418-423 pts_max). perturb>0 <=> t_rand given; det sampling <=> u is None."""
+                t_rand=None, u=None, D=8, W=256, lindisp=False, want_pts_max=True, return_weights=False,
+                noise=None, noise_fine=None):
+    """RN:308-418 (+ NC:418-423 pts_max). perturb>0 <=> t_rand given; det sampling <=> u is None;
+    noise / noise_fine = the (already scaled) raw_noise_std draws of RN:285 for the coarse / fine composite."""
     ray_batch = np.asarray(ray_batch, F32)
     rays_o, rays_d = ray_batch[:, 0:3], ray_batch[:, 3:6]
     viewdirs = ray_batch[:, -3:]
@@ -182,7 +184,7 @@ def render_rays(ray_batch, sd_coarse, N_samples, N_importance=0, sd_fine=None, w
     z_vals = coarse_z_vals(near, far, N_samples, t_rand, lindisp)
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)
     raw = run_network(sd_coarse, pts, viewdirs, D=D, W=W)
-    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, None, white_bkgd)
+    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, noise, white_bkgd)
     ret = {}
     if N_importance > 0:
         ret.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
@@ -193,7 +195,7 @@ def render_rays(ray_batch, sd_coarse, N_samples, N_importance=0, sd_fine=None, w
         z_vals = np.sort(np.concatenate([z_vals, z_samples], -1), -1)
         pts = (rays_o[:, None, :] + rays_d[:, None, :] * z_vals[:, :, None]).astype(F32)
         raw = run_network(sd_fine if sd_fine is not None else sd_coarse, pts, viewdirs, D=D, W=W)
-        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, None, white_bkgd)
+        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(raw, z_vals, rays_d, noise_fine, white_bkgd)
         zs = z_samples.astype(F32)
         mean = zs.mean(-1, keepdims=True, dtype=F32)
         ret['z_std'] = np.sqrt(((zs - mean) ** 2).mean(-1, dtype=F32)).astype(F32)   # RN:412

@@ -513,8 +513,65 @@ def g13():
     save('g13_adam', **out)
 
 
+def g14():
+    """Less-travelled options of render_rays / render, from the reference itself: lindisp sampling, raw_noise_std > 0
+    (RN:285), white_bkgd=False, the pytest=True numpy-seed-0 overrides (RN:374-377, RN:288-291, RH:215-223),
+    c2w_staticcam (RN:105-107) and a caller-provided ray batch (RN:86-88)."""
+    out = {}
+    e10, _ = RH.get_embedder(10, 0)
+    e4, _ = RH.get_embedder(4, 0)
+
+    def query(inputs, viewdirs, network_fn):
+        return RN.run_network(inputs, viewdirs, network_fn, embed_fn=e10, embeddirs_fn=e4, netchunk=1024 * 64)
+    R = 24
+    rays = synth.ray_batch(R, seed=140)
+    coarse, fine = make_net(4, 64, 141), make_net(4, 64, 142)
+    out['rays'] = rays
+    out['seed_coarse'], out['seed_fine'] = 141, 142
+    # (a) lindisp + perturb + noise, explicit draws; black background
+    g = torch.Generator().manual_seed(14)
+    t_rand = torch.rand((R, 64), generator=g)
+    u = torch.rand((R, 128), generator=g)
+    n0 = torch.randn((R, 64), generator=g)
+    n1 = torch.randn((R, 192), generator=g)
+    orig_rand, orig_randn = torch.rand, torch.randn
+    torch.rand = FixedRand([t_rand, u])
+    torch.randn = FixedRand([n0, n1])
+    try:
+        with torch.no_grad():
+            r = NC.render_rays(T(rays), coarse, query, 64, retraw=True, lindisp=True, perturb=1., N_importance=128,
+                               network_fine=fine, white_bkgd=False, raw_noise_std=1.0)
+    finally:
+        torch.rand, torch.randn = orig_rand, orig_randn
+    out.update({'a_' + k: v.numpy() for k, v in r.items()})
+    out.update(a_t_rand=t_rand.numpy(), a_u=u.numpy(), a_noise0=n0.numpy(), a_noise1=n1.numpy())
+    # (b) pytest=True: every draw comes from numpy seeded with 0 inside the reference
+    with torch.no_grad():
+        r = NC.render_rays(T(rays), coarse, query, 64, retraw=True, perturb=1., N_importance=128, network_fine=fine,
+                           white_bkgd=True, raw_noise_std=0.5, pytest=True)
+    out.update({'b_' + k: v.numpy() for k, v in r.items()})
+    # (c) render(): static camera and caller-provided rays
+    H = 6
+    focal, K = synth.lego_intrinsics(H, H)
+    c2w = synth.pose_spherical(70.0, -20.0, 4.0)[:3, :4]
+    c2w_s = synth.pose_spherical(-40.0, -35.0, 4.0)[:3, :4]
+    kw = dict(network_query_fn=query, perturb=0., N_importance=128, network_fine=fine, N_samples=64,
+              network_fn=coarse, use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+    with torch.no_grad():
+        rgb, disp, acc, pts_max, extras = NC.render(H, H, K, chunk=16, c2w=T(c2w), c2w_staticcam=T(c2w_s), near=2., far=6., **kw)
+        ro, rd = RH.get_rays(H, H, K, T(c2w))
+        sel = torch.tensor([0, 7, 13, 35])
+        batch_rays = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+        rgb2, disp2, acc2, extras2 = RN.render(H, H, K, chunk=3, rays=batch_rays, near=2., far=6., **kw)
+    out.update(c_K=K, c_c2w=c2w, c_c2w_static=c2w_s, c_rgb=rgb.numpy(), c_disp=disp.numpy(), c_acc=acc.numpy(),
+               c_pts_max=pts_max.numpy(), c_z_std=extras['z_std'].numpy(),
+               c_batch_rays=batch_rays.numpy(), c_rays_rgb=rgb2.numpy(), c_rays_disp=disp2.numpy(), c_rays_acc=acc2.numpy(),
+               c_rays_rgb0=extras2['rgb0'].numpy())
+    save('g14_render_options', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14']
     for w in which:
         globals()[w]()
 

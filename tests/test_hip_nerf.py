@@ -242,3 +242,34 @@ def test_cpu_tensors_are_moved_not_computed_on_cpu():
     from nerfail_amd.run_nerf import raw2outputs
     out = raw2outputs(torch.zeros(2, 64, 4), torch.linspace(2, 6, 64).repeat(2, 1), torch.ones(2, 3))
     assert out[0].is_cuda
+
+
+def test_render_options_match_reference(golden):
+    """Options the shipped configs leave at their defaults, against the reference's own output (fixture g14): lindisp,
+    raw_noise_std > 0 with explicit draws, black background; the pytest=True numpy-seed-0 overrides; c2w_staticcam and
+    a caller-provided ray batch through render()."""
+    from nerfail_amd import nerf_to_coord as NC, run_nerf as RN
+    g = golden('g14_render_options')
+    _, coarse = hip_nerf(4, 64, int(g['seed_coarse']))
+    _, fine = hip_nerf(4, 64, int(g['seed_fine']))
+    keys = ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'pts_max')
+    r = NC.render_rays(T(g['rays']), coarse, None, 64, retraw=True, lindisp=True, perturb=1., N_importance=128,
+                       network_fine=fine, white_bkgd=False, raw_noise_std=1.0, t_rand=T(g['a_t_rand']), u=T(g['a_u']),
+                       noise=T(g['a_noise0']), noise_fine=T(g['a_noise1']))
+    for k in keys:
+        assert rel_err(N(r[k]), g['a_' + k]) < 1e-4, k
+    r = NC.render_rays(T(g['rays']), coarse, None, 64, retraw=True, perturb=1., N_importance=128, network_fine=fine,
+                       white_bkgd=True, raw_noise_std=0.5, pytest=True)
+    for k in keys:
+        assert rel_err(N(r[k]), g['b_' + k]) < 1e-4, k
+    q = RN.FusedNetworkQuery(RN.get_embedder(10, 0)[0], RN.get_embedder(4, 0)[0])
+    kw = dict(network_query_fn=q, perturb=0., N_importance=128, network_fine=fine, N_samples=64, network_fn=coarse,
+              use_viewdirs=True, white_bkgd=True, raw_noise_std=0., ndc=False, lindisp=False)
+    rgb, disp, acc, pts_max, extras = NC.render(6, 6, g['c_K'], chunk=16, c2w=T(g['c_c2w']), c2w_staticcam=T(g['c_c2w_static']),
+                                                near=2., far=6., **kw)
+    for v, gk in ((rgb, 'c_rgb'), (disp, 'c_disp'), (acc, 'c_acc'), (pts_max, 'c_pts_max'), (extras['z_std'], 'c_z_std')):
+        assert rel_err(N(v), g[gk]) < 1e-4, gk
+    out = RN.render(6, 6, g['c_K'], chunk=3, rays=T(g['c_batch_rays']), near=2., far=6., **kw)
+    assert tuple(out[0].shape) == (4, 3)
+    for v, gk in ((out[0], 'c_rays_rgb'), (out[1], 'c_rays_disp'), (out[2], 'c_rays_acc'), (out[3]['rgb0'], 'c_rays_rgb0')):
+        assert rel_err(N(v), g[gk]) < 1e-4, gk

@@ -140,3 +140,25 @@ def test_train_step_grads_match_reference_autograd(golden):
                     refn = float(g['full_%s_gradnorm_%s' % (nm, k)])
                     assert abs(np.linalg.norm(v.astype(np.float64)) - refn) < 5e-3 * refn, (nm, k)
                     assert l2_err(v.reshape(-1)[:256], g['full_%s_gradhead_%s' % (nm, k)]) < 5e-3, (nm, k)
+
+
+def test_render_options_match_reference(golden):
+    """lindisp sampling, raw_noise_std draws, black background (fixture g14a) and the pytest=True numpy-seed-0 draws
+    (g14b: RN:374-377 t_rand, RH:215-223 u, RN:288-291 noise - each re-seeded with 0 right before its draw)."""
+    g = golden('g14_render_options')
+    sc, sf = synth.nerf_state_dict(D=4, W=64, seed=int(g['seed_coarse'])), synth.nerf_state_dict(D=4, W=64, seed=int(g['seed_fine']))
+    keys = ('rgb_map', 'disp_map', 'acc_map', 'rgb0', 'disp0', 'acc0', 'z_std', 'pts_max')
+    r = O.render_rays(g['rays'], sc, 64, 128, sf, white_bkgd=False, t_rand=g['a_t_rand'], u=g['a_u'], D=4, W=64, lindisp=True,
+                      noise=g['a_noise0'] * np.float32(1.0), noise_fine=g['a_noise1'] * np.float32(1.0))
+    for k in keys:
+        assert rel_err(r[k], g['a_' + k]) < 1e-4, k
+    R = g['rays'].shape[0]
+
+    def draw(*shape):
+        np.random.seed(0)
+        return np.random.rand(*shape)
+    r = O.render_rays(g['rays'], sc, 64, 128, sf, white_bkgd=True, t_rand=draw(R, 64).astype(np.float32),
+                      u=draw(R, 128).astype(np.float32), D=4, W=64,
+                      noise=(draw(R, 64) * 0.5).astype(np.float32), noise_fine=(draw(R, 192) * 0.5).astype(np.float32))
+    for k in keys:
+        assert rel_err(r[k], g['b_' + k]) < 1e-4, k
