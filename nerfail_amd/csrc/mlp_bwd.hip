@@ -480,7 +480,7 @@ struct LArgs {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MA, int NB, int LA, int LB>
+template <bool BF16, int MA, int NB, int LA, int LB>
 __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, float* smem, int lane, int wave,
                                              long t_begin, long t_end) {
     constexpr int NPIECE = 2 * (LA + LB), G = (NPIECE + 3) / 4, NS = kLdsStages;
@@ -536,33 +536,58 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
         __builtin_amdgcn_s_barrier();                                   // ... everyone's have; and stage s-1 is no longer read
         issue(s + NS - 1, rs_issue);
         const float* __restrict__ st = smem + rs_read * kLdsStageFloats;
-        u32x4b ah[MA], al[MA], bh[NB], bl[NB];
+        if constexpr (BF16) {
+            u32x4b ah[MA], al[MA], bh[NB], bl[NB];
 #pragma unroll
-        for (int m = 0; m < MA; ++m) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd0);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd1);
-            if (NF_DW_ABLATE == 2) { ah[m] = __builtin_bit_cast(u32x4b, v0); al[m] = __builtin_bit_cast(u32x4b, v1); }
-            else split_bf16(v0, v1, ah[m], al[m]);
-            if (do_bias) rowsum[m] += (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+            for (int m = 0; m < MA; ++m) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd0);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd1);
+                if (NF_DW_ABLATE == 2) { ah[m] = __builtin_bit_cast(u32x4b, v0); al[m] = __builtin_bit_cast(u32x4b, v1); }
+                else split_bf16(v0, v1, ah[m], al[m]);
+                if (do_bias) rowsum[m] += (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd0);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd1);
+                if (NF_DW_ABLATE == 2) { bh[n] = __builtin_bit_cast(u32x4b, v0); bl[n] = __builtin_bit_cast(u32x4b, v1); }
+                else split_bf16(v0, v1, bh[n], bl[n]);
+            }
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int m = 0; m < MA; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        const bf8 A_ = __builtin_bit_cast(bf8, x == 2 ? al[m] : ah[m]);
+                        const bf8 B_ = __builtin_bit_cast(bf8, x == 1 ? bl[n] : bh[n]);
+                        if (NF_DW_ABLATE != 3) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[m][n], 0, 0, 0);
+                        else acc[m][n][(x * 5 + m + n) & 15] += __uint_as_float(A_[0] == B_[1] ? 1u : 0u);   // keep the operands alive
+                    }
+        } else {
+            // exact-f32 form: the 8 samples a lane holds are 8 k-steps of v_mfma_f32_32x32x2_f32 (k = (step, kh) <-> sample
+            // 8*kh + step inside the k16-step: any bijection works as long as A and B use the same one)
+            f32x4 av[MA][2], bv[NB][2];
+#pragma unroll
+            for (int m = 0; m < MA; ++m) {
+                av[m][0] = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd0);
+                av[m][1] = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd1);
+                if (do_bias) rowsum[m] += (av[m][0][0] + av[m][0][1]) + (av[m][0][2] + av[m][0][3]) +
+                                          (av[m][1][0] + av[m][1][1]) + (av[m][1][2] + av[m][1][3]);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                bv[n][0] = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd0);
+                bv[n][1] = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd1);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int m = 0; m < MA; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e >> 2][e & 3], bv[n][e >> 2][e & 3], acc[m][n], 0, 0, 0);
         }
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd0);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd1);
-            if (NF_DW_ABLATE == 2) { bh[n] = __builtin_bit_cast(u32x4b, v0); bl[n] = __builtin_bit_cast(u32x4b, v1); }
-            else split_bf16(v0, v1, bh[n], bl[n]);
-        }
-#pragma unroll
-        for (int x = 0; x < 3; ++x)
-#pragma unroll
-            for (int m = 0; m < MA; ++m)
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    const bf8 A_ = __builtin_bit_cast(bf8, x == 2 ? al[m] : ah[m]);
-                    const bf8 B_ = __builtin_bit_cast(bf8, x == 1 ? bl[n] : bh[n]);
-                    if (NF_DW_ABLATE != 3) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[m][n], 0, 0, 0);
-                    else acc[m][n][(x * 5 + m + n) & 15] += __uint_as_float(A_[0] == B_[1] ? 1u : 0u);   // keep the operands alive
-                }
         rs_read = (rs_read + 1) & (NS - 1);
         rs_issue = (rs_issue + 1) & (NS - 1);
     }
@@ -596,6 +621,7 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
 // group shapes of a W = 256 network: <MA, NB, LA, LB>
 //   0 full 256x256 layer-part <4,4,8,8>   1 views (128 x 256) <4,2,4,8>   2 encoding columns (256 x 63) <2,2,8,2>
 //   3 view-direction columns (128 x 27) <1,1,4,1>   4 rgb head (3 x 128) <1,1,1,4>   5 alpha head (1 x 256) <1,2,1,8>
+template <bool BF16>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_lds_kernel(LArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[kLdsStages * kLdsStageFloats];
     const int lane = threadIdx.x & 63;
@@ -612,12 +638,12 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_lds_kernel(LArgs 
         if (t_begin >= t_end) continue;
         const LGroup& grp = a.grp[g];
         switch (grp.shape) {
-            case 0: dw_group_lds<4, 4, 8, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
-            case 1: dw_group_lds<4, 2, 4, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
-            case 2: dw_group_lds<2, 2, 8, 2>(a, grp, smem, lane, wave, t_begin, t_end); break;
-            case 3: dw_group_lds<1, 1, 4, 1>(a, grp, smem, lane, wave, t_begin, t_end); break;
-            case 4: dw_group_lds<1, 1, 1, 4>(a, grp, smem, lane, wave, t_begin, t_end); break;
-            default: dw_group_lds<1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 0: dw_group_lds<BF16, 4, 4, 8, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 1: dw_group_lds<BF16, 4, 2, 4, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 2: dw_group_lds<BF16, 2, 2, 8, 2>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 3: dw_group_lds<BF16, 1, 1, 4, 1>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            case 4: dw_group_lds<BF16, 1, 1, 1, 4>(a, grp, smem, lane, wave, t_begin, t_end); break;
+            default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
         }
     }
 }
@@ -771,12 +797,13 @@ static int bwd_weights_impl(int D, int W, int skip, const float* acts, const flo
         part(d, TL.a_H1 + (D - 1) * NT, NT, 0, 0, W);
     }
     a.ndesc = nd;
-    // NERFAIL_DW_KERNEL=lds selects the LDS-staged kernel. It is NOT faster: both kernels move the same 4.3 GB per
-    // 196 608 samples and both sit at the ~4 TB/s this access pattern gets from HBM (measured 1.12 vs 1.21 ms;
-    // without its loads the LDS kernel needs 0.42 ms). Kept as the tested starting point for when the bytes shrink.
+    // Kernel choice (W = 256): exact-f32 weight gradients run on the LDS-staged kernel (MFMA bound, the staging keeps the
+    // pipe fed), the bf16x3 form on the register-fed kernel (both forms of it move the same 4.3 GB per 196 608 samples
+    // and sit at the ~4 TB/s this access pattern gets from HBM: 1.12 vs 1.21 ms; without its loads the LDS kernel
+    // needs 0.42 ms). NERFAIL_DW_KERNEL=reg | lds forces one for A/B timing and for the parity tests of both.
     const char* dwk = getenv("NERFAIL_DW_KERNEL");
-    const bool use_lds = dwk != nullptr && dwk[0] == 'l';
-    if (bf16x3 && NT == 8 && use_lds) {   // LDS-staged kernel: one group per layer-part, in descriptor order
+    const bool use_lds = dwk != nullptr ? dwk[0] == 'l' : !bf16x3;
+    if (NT == 8 && use_lds) {   // LDS-staged kernel: one group per layer-part, in descriptor order
         LArgs la;
         la.acts = acts; la.dz = dz; la.ntiles = a.ntiles; la.a_slots = a.a_slots; la.z_slots = a.z_slots;
         for (int di = 0; di < nd; ++di) la.desc[di] = a.desc[di];
@@ -793,20 +820,21 @@ static int bwd_weights_impl(int D, int W, int skip, const float* acts, const flo
                 else if (LA == 4 && LB == 1) { shape = 3; ma = 1; nb = 1; }
                 else if (LA == 1 && LB == 4) { shape = 4; ma = 1; nb = 1; }
                 else if (LA == 1 && LB == 8) { shape = 5; ma = 1; nb = 2; }
-                else { set_error("nerfail_mlp_bwd_weights_bf16x3: unexpected layer shape"); return NERFAIL_EINVAL; }
+                else { set_error("nerfail_mlp_bwd_weights: unexpected layer shape for the LDS-staged kernel"); return NERFAIL_EINVAL; }
                 NF_REQUIRE(ng < kMaxLGroups, "too many weight-gradient groups");
                 LGroup& g = la.grp[ng];
                 g.desc = di; g.part = p; g.dz_slot0 = d.dz_slot0; g.x_slot0 = d.parts[p].slot0; g.shape = shape;
                 const int G = (2 * (LA + LB) + 3) / 4;
-                la.cost[ng] = 96 * ma * nb + 70 * G + 150;          // cycles per k16-step: 3 MFMAs x 32 per tile pair + staging
+                la.cost[ng] = (bf16x3 ? 96 : 512) * ma * nb + 70 * G + 150;   // cycles per k16-step: 3 x 32 (bf16) or 8 x 64 (f32) per tile pair + staging
                 la.cum[ng + 1] = la.cum[ng] + (long)la.cost[ng] * la.ntiles;
                 ++ng;
             }
         la.ngroups = ng;
         long wgs = cu_count();
-        const long min_units = 2246L * 4;                          // at least ~4 full-layer tiles per workgroup
+        const long min_units = (bf16x3 ? 2246L : 8902L) * 4;       // at least ~4 full-layer tiles per workgroup
         if (wgs > la.cum[ng] / min_units) wgs = la.cum[ng] / min_units > 0 ? la.cum[ng] / min_units : 1;
-        nerf_mlp_bwd_weights_lds_kernel<<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(la);
+        if (bf16x3) nerf_mlp_bwd_weights_lds_kernel<true><<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(la);
+        else nerf_mlp_bwd_weights_lds_kernel<false><<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(la);
         NF_LAUNCHED("nerf_mlp_bwd_weights_lds_kernel");
         return NERFAIL_OK;
     }

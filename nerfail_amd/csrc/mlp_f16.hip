@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
                         if (TRAIN && save) {
                             const int r = 8 * sgrp + q;
                             lpA[(slot0 + t) * 1024 + acc_reg_off(r)] = v[q];
-                            mk.w[t >> 1] |= (v[q] > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+                            mk.w[t >> 1] |= relu_bit(v[q]) << (16 * (t & 1) + r);
                         }
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
                 for (int r = 0; r < 16; ++r) {
                     const float x = fmaxf(hv[t][r] * kWInv, 0.f);
                     lpA[(3 + (L.D + 1) * NT + t) * 1024 + acc_reg_off(r)] = x;
-                    mk.w[t >> 1] |= (x > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+                    mk.w[t >> 1] |= relu_bit(x) << (16 * (t & 1) + r);
                 }
             store_mask<OTV>(A + train_mask_slot0(L.D, NT) * 1024, L.D, mk, lane);
         }

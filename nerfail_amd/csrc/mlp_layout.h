@@ -101,10 +101,18 @@ static inline void make_layout_T(int D, int NT, MlpLayoutT& L) {
 }
 
 // ---- device helpers shared by the forward and backward kernels -------------------------------------------
+#ifndef NF_FWD_ABLATE
+#define NF_FWD_ABLATE 0     // timing experiments (tools/ablate.py): 1 no bias loads, 2 no exposed first weight quad, 3 no encoding, 4 no weight stream (registers rotate), 5 weight stream re-reads quads 0/1 (L1-hot), 9 clock probe
+#endif
 template <int OT>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __restrict__ b, int h) {
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
+        if (NF_FWD_ABLATE == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            continue;
+        }
         const f32x4* p = reinterpret_cast<const f32x4*>(b + (t * 2 + h) * 16);
         const f32x4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
         acc[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
@@ -113,22 +121,43 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __rest
 }
 
 // One part of a layer: NQ quads of 4 k-steps. Quad q's A fragments (one 16-byte load per out-tile and
-// lane) are requested one quad AHEAD of the 4*OT MFMAs that consume them, so the ~2048 MFMA cycles of a
-// quad cover the L2 latency of the next one (one wave per SIMD: nothing else would hide it).
+// lane) are requested PFQ (default NF_MLP_PF = 1) quads AHEAD of the 4*OT MFMAs that consume them, so ~2048 MFMA cycles per quad
+// of distance cover the L2 latency (one wave per SIMD: nothing else would hide it).
 // bsel(q, e) yields the B operand (a register of the previous layer / of the encoding) for k-step 4q+e;
 // q and e are compile-time constants after unrolling, so it is a plain register reference.
-template <int OT, int NQ, typename BSel>
+#ifndef NF_MLP_PF
+#define NF_MLP_PF 1          // quads of A fragments in flight ahead of the one being multiplied
+#endif
+#if 0
+// What the exact-f32 forward kernel loses against the 154.8 TFLOP/s the bare MFMA loop sustains on this chip (clock
+// 2.387 GHz inside the kernel, no throttling - tools/clockprobe, tools/fwd_clock.py), measured by ablation
+// (tools/ablate.py, NF_FWD_ABLATE) at 1.57 M samples, 14.14 ms = 132 TFLOP/s:
+//   weight stream served from L1 instead of L2 (re-reading quads 0/1)   13.13 ms   -> 6.5 % is L2 -> CU delivery
+//   no weight stream at all (registers rotate)                          13.23 ms      (i.e. not instruction issue)
+//   no positional encoding                                              13.92 ms   -> 2 %
+//   no bias loads / no exposed first quad of a part                     14.08 / 14.11 ms -> 1 % each
+//   rest (ReLU, accumulator shuffles at layer boundaries, heads)        ~5 %
+// Tried against the 6.5 %: a ring 2 quads ahead (no change even with the encodings parked in LDS so that nothing
+// spills in the loop: the limit is delivery rate, not latency) and lock-stepping the 4 waves with one s_barrier per
+// quad so that one L2 fetch serves all four from L1 (17.9 ms: a barrier couples every wave to the slowest one).
+#endif
+template <int OT, int NQ, int PFQ = NF_MLP_PF, typename BSel>
 __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __restrict__ w, int lane, BSel bsel) {
     const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
-    f32x4 cur[OT], nxt[OT];
+    constexpr int PF = PFQ < NQ ? PFQ : (NQ > 1 ? NQ - 1 : 1), RING = PF + 1;
+    f32x4 ring[RING][OT];      // indices are compile-time constants after unrolling: plain registers, no copies
 #pragma unroll
-    for (int t = 0; t < OT; ++t) cur[t] = wp[t * 64];
+    for (int p = 0; p < PF && p < NQ; ++p)
+#pragma unroll
+        for (int t = 0; t < OT; ++t) ring[p][t] = (NF_FWD_ABLATE == 2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : wp[(p * OT + t) * 64];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        if (q + 1 < NQ) {
+        if (q + PF < NQ) {
 #pragma unroll
-            for (int t = 0; t < OT; ++t) nxt[t] = wp[((q + 1) * OT + t) * 64];
-            // Pin the software pipeline: nothing may be scheduled across this point, so the loads of quad q+1 stay
+            for (int t = 0; t < OT; ++t)
+                ring[(q + PF) % RING][t] = (NF_FWD_ABLATE == 4) ? (f32x4){ring[q % RING][t][1], ring[q % RING][t][2], ring[q % RING][t][3], ring[q % RING][t][0]}
+                                                                : wp[(((NF_FWD_ABLATE == 5) ? (q & 1) : (q + PF)) * OT + t) * 64];
+            // Pin the software pipeline: nothing may be scheduled across this point, so the loads of quad q+PF stay
             // AHEAD of the 4*OT MFMAs of quad q (under register pressure the scheduler otherwise sinks them next to
             // their use and every quad waits vmcnt(0) on an exposed L2 round trip).
             __builtin_amdgcn_sched_barrier(0);
@@ -137,26 +166,22 @@ __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __rest
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < OT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][e], bsel(q, e), acc[t], 0, 0, 0);
-        if (q + 1 < NQ) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < OT; ++t) cur[t] = nxt[t];
-        }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[q % RING][t][e], bsel(q, e), acc[t], 0, 0, 0);
+        if (q + PF < NQ) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int OT, int NQ>
+template <int OT, int NQ, int PFQ = NF_MLP_PF>
 __device__ __forceinline__ void mfma_scalars(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
                                              const float (&bsrc)[4 * NQ]) {
-    mfma_part<OT, NQ>(acc, w, lane, [&](int q, int e) { return bsrc[4 * q + e]; });
+    mfma_part<OT, NQ, PFQ>(acc, w, lane, [&](int q, int e) { return bsrc[4 * q + e]; });
 }
 
 // NT*4 quads whose B operands are the previous layer's accumulator registers
-template <int OT, int NT>
+template <int OT, int NT, int PFQ = NF_MLP_PF>
 __device__ __forceinline__ void mfma_acts(f32x16 (&acc)[OT], const float* __restrict__ w, int lane,
                                           const f32x16 (&in)[NT]) {
-    mfma_part<OT, NT * 4>(acc, w, lane, [&](int q, int e) { return in[q >> 2][4 * (q & 3) + e]; });
+    mfma_part<OT, NT * 4, PFQ>(acc, w, lane, [&](int q, int e) { return in[q >> 2][4 * (q & 3) + e]; });
 }
 
 template <int NT>
@@ -204,6 +229,13 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int 
 template <int NTILES>
 struct TileMask { unsigned w[(NTILES + 1) / 2]; };
 
+// 1 where a post-ReLU value is > +0, else 0 - as integer clamp of the float's bit pattern (v_med3_i32, no trip through
+// VCC; -0 and +0 give 0). A compare + select per element measured 7 % of the training forward.
+__device__ __forceinline__ unsigned relu_bit(float a) {
+    unsigned b;      // inline asm: hipcc rewrites min(max(x, 0), 1) into compare + select
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b) : "v"(a));
+    return b;
+}
 template <int NTILES>
 __device__ __forceinline__ TileMask<NTILES> mask_of(const f32x16 (&a)[NTILES]) {
     TileMask<NTILES> m;
@@ -212,7 +244,7 @@ __device__ __forceinline__ TileMask<NTILES> mask_of(const f32x16 (&a)[NTILES]) {
 #pragma unroll
     for (int t = 0; t < NTILES; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m.w[t >> 1] |= (a[t][r] > 0.f ? 1u : 0u) << (16 * (t & 1) + r);
+        for (int r = 0; r < 16; ++r) m.w[t >> 1] |= relu_bit(a[t][r]) << (16 * (t & 1) + r);
     return m;
 }
 template <int NTILES>
