@@ -121,14 +121,13 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __rest
 }
 
 // One part of a layer: NQ quads of 4 k-steps. Quad q's A fragments (one 16-byte load per out-tile and
-// lane) are requested PFQ (default NF_MLP_PF = 1) quads AHEAD of the 4*OT MFMAs that consume them, so ~2048 MFMA cycles per quad
-// of distance cover the L2 latency (one wave per SIMD: nothing else would hide it).
+// lane) are requested PFQ (default NF_MLP_PF = 1) quads AHEAD of the 4*OT MFMAs that consume them, so ~2048 MFMA
+// cycles per quad of distance cover the L2 latency (one wave per SIMD: nothing else would hide it).
 // bsel(q, e) yields the B operand (a register of the previous layer / of the encoding) for k-step 4q+e;
 // q and e are compile-time constants after unrolling, so it is a plain register reference.
 #ifndef NF_MLP_PF
 #define NF_MLP_PF 1          // quads of A fragments in flight ahead of the one being multiplied
 #endif
-#if 0
 // What the exact-f32 forward kernel loses against the 154.8 TFLOP/s the bare MFMA loop sustains on this chip (clock
 // 2.387 GHz inside the kernel, no throttling - tools/clockprobe, tools/fwd_clock.py), measured by ablation
 // (tools/ablate.py, NF_FWD_ABLATE) at 1.57 M samples, 14.14 ms = 132 TFLOP/s:
@@ -140,7 +139,6 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __rest
 // Tried against the 6.5 %: a ring 2 quads ahead (no change even with the encodings parked in LDS so that nothing
 // spills in the loop: the limit is delivery rate, not latency) and lock-stepping the 4 waves with one s_barrier per
 // quad so that one L2 fetch serves all four from L1 (17.9 ms: a barrier couples every wave to the slowest one).
-#endif
 template <int OT, int NQ, int PFQ = NF_MLP_PF, typename BSel>
 __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __restrict__ w, int lane, BSel bsel) {
     const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
