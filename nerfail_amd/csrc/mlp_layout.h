@@ -138,7 +138,8 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __rest
 //   rest (ReLU, accumulator shuffles at layer boundaries, heads)        ~5 %
 // Tried against the 6.5 %: a ring 2 quads ahead (no change even with the encodings parked in LDS so that nothing
 // spills in the loop: the limit is delivery rate, not latency) and lock-stepping the 4 waves with one s_barrier per
-// quad so that one L2 fetch serves all four from L1 (17.9 ms: a barrier couples every wave to the slowest one).
+// quad so that one L2 fetch serves all four from L1 (17.9 ms: a barrier couples every wave to the slowest one; one
+// barrier per layer: 16.2 ms - aligned waves miss L1 together, free-running ones already share it by drifting).
 template <int OT, int NQ, int PFQ = NF_MLP_PF, typename BSel>
 __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __restrict__ w, int lane, BSel bsel) {
     const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
