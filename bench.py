@@ -251,6 +251,11 @@ def attack_bench(dev, iters=5):
     dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
     out['end_to_end_victim_cnn'] = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
                                     'note': 'gauss_net.forward (2 classifier forwards) + CE + backward + sign step'}
+    net.cache_ori_cla = True                       # the unperturbed images' logits never change in the loop
+    dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
+    out['end_to_end_victim_cnn_cached_original_logits'] = {
+        'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
+        'note': 'same, gauss_net.cache_ori_cla = True (1 classifier forward per step; identical results)'}
     out['batch_views'] = B
     out['unit'] = 'NeRFail-S iterations/s (batch of 8 views, 800x800, P=3)'
     return out

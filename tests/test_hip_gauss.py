@@ -105,3 +105,40 @@ def test_gauss_full_size_properties():
     xs, xr, _ = OG.gauss_forward(N(s1), N(wi)[:, :, 400:401], N(ori)[:, 400:401], 32.0)
     xh, xrh = gauss_gather(s1, wi[:, :, 400:401].contiguous(), ori[:, 400:401].contiguous(), 32.0)
     assert rel_err(N(xh), xs) < 1e-5 and rel_err(N(xrh), xr) < 1e-5
+
+
+def test_cached_original_logits_are_identical():
+    """gauss_net.cache_ori_cla: same 5-tuple as the reference-shaped forward, the second call reuses the
+    stored logits of the unperturbed images, a modified image tensor invalidates them."""
+    from nerfail_amd.GaussNet import gauss_net, create_gauss_w
+    rs = np.random.RandomState(3)
+    P, B, H, W = 3, 2, 12, 12
+    s = T(rs.uniform(-20, 20, (P, H, W, 4)).astype(np.float32))
+    ori = T(synth.disc_alpha_image(B, H, W, seed=2))
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, (B, H, W, 8)).astype(np.float32)
+    wi, _ = create_gauss_w(dev(), 0.02)(T(np.stack([dist, idx], 1)))
+    torch.manual_seed(1)
+    calls = []
+
+    class Cls(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3 * 4 * 4, 8)
+
+        def forward(self, x):
+            calls.append(x.shape[0])
+            return self.lin(torch.nn.functional.adaptive_avg_pool2d(x, 4).reshape(x.shape[0], -1))
+    net = gauss_net(dev(), 0.02, Cls().to(dev()), 'my_model', epsilon=None)
+    ref = net(s, wi, ori)
+    net.cache_ori_cla = True
+    calls.clear()
+    a = net(s, wi, ori)
+    b = net(s, wi, ori)
+    assert len(calls) == 3                                   # 2 + 1: the second forward skipped the original images
+    for r, x, y in zip(ref, a, b):
+        assert torch.equal(r, x) and torch.equal(r, y)
+    ori.mul_(0.5)                                            # in-place change -> new version -> recomputed
+    calls.clear()
+    c = net(s, wi, ori)
+    assert len(calls) == 2 and not torch.equal(c[4], ref[4])
