@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be imported first: libnerfail_hip.so binds to torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnerfail_hip.so')
+LIB_PATH = os.environ.get('NERFAIL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerfail_hip.so')   # override: A/B builds (tools/ablate.py)
 
 ABI_VERSION = 1
 MAX_DEPTH = 16

@@ -95,7 +95,15 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __r
 //     thrash, ~30x read amplification.
 //   * The trip count is WAVE-UNIFORM (max row length of the wave) and all loads are unconditional (clamped index,
 //     weight 0 past the row's end), so the 4x unrolled loop keeps the 16-byte gathers of 4 contributions in flight.
-constexpr int kRowCap = 2048;    // index entries staged per wave (16 KB of LDS); longer ranges take the direct path
+// Gathers in flight per lane and loop iteration. The row walk is latency bound (16-byte gathers out of an 80 MB
+// array): 4 -> 1.74 ms per 8-view iteration, 8 -> 1.58, 16 -> 1.42, 32 (a whole typical row at once) -> 1.33.
+#ifndef NF_ROW_UNROLL
+#define NF_ROW_UNROLL 32
+#endif
+#ifndef NF_ROW_CAP
+#define NF_ROW_CAP 2048
+#endif
+constexpr int kRowCap = NF_ROW_CAP;    // index entries staged per wave (8 B each in LDS); longer ranges take the direct path
 
 __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __restrict__ row_ptr, const int* __restrict__ contrib,
                                                                const float* __restrict__ w_sorted,
@@ -124,22 +132,23 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __rest
         __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes before its reads
     }
     const int r0 = c0 - base;
-    for (int k = 0; k < maxlen; k += 4) {
-        int id[4];
-        float w[4];
+    constexpr int U = NF_ROW_UNROLL;               // gathers in flight per lane and iteration
+    for (int k = 0; k < maxlen; k += U) {
+        int id[U];
+        float w[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const bool ok = k + u < len;
             const int c = ok ? r0 + k + u : 0;
             if (staged) { id[u] = s_id[wv][c]; w[u] = s_w[wv][c]; }
             else { id[u] = contrib[base + c]; w[u] = w_sorted[base + c]; }
             if (!ok) w[u] = 0.f;
         }
-        float4 g[4];
+        float4 g[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) g[u] = g_pix[id[u] >> 3];
+        for (int u = 0; u < U; ++u) g[u] = g_pix[id[u] >> 3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (k + u < len) {                     // keeps 0 * inf / NaN of a foreign row out of the sum
                 acc.x += w[u] * g[u].x; acc.y += w[u] * g[u].y; acc.z += w[u] * g[u].z; acc.w += w[u] * g[u].w;
             }
@@ -222,24 +231,25 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_multi_kernel(const int* 
         __builtin_amdgcn_s_waitcnt(0xc07f);
     }
     const int r0 = c0 - base;
-    for (int k = 0; k < maxlen; k += 2) {          // same contribution order per row as the single-RHS kernel => same bits
-        int id[2];
-        float w[2];
+    constexpr int U = 4;
+    for (int k = 0; k < maxlen; k += U) {          // same contribution order per row as the single-RHS kernel => same bits
+        int id[U];
+        float w[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const bool ok = k + u < len;
             const int c = ok ? r0 + k + u : 0;
             if (staged) { id[u] = s_id[wv][c]; w[u] = s_w[wv][c]; }
             else { id[u] = contrib[base + c]; w[u] = w_sorted[base + c]; }
             if (!ok) w[u] = 0.f;
         }
-        float4 g[2][C];
+        float4 g[U][C];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> 3) * C + c];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (k + u < len) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -258,7 +268,7 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t cub_temp_bytes(long n) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                                        (int*)nullptr, (int)n, 0, 32, (hipStream_t) nullptr);
     return bytes;
 }
