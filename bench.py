@@ -108,14 +108,19 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
         step()
     torch.cuda.synchronize()
     t = time.time()
-    for _ in range(steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
+    for i in range(steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dt = (time.time() - t) / steps
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     evals = n_rand * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)                           # coarse + fine network evaluations
     flop = evals * FLOP_PER_SAMPLE * 3                                                # fwd + bwd-data + bwd-weights
     out = {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand, 'precision': precision,
-           'final_loss': float(loss.detach()), 'fp32_equivalent_tflops_whole_step': flop / dt / 1e12}
+           'final_loss': float(loss.detach()), 'fp32_equivalent_tflops_whole_step': flop / dt / 1e12,
+           'ms_per_step_each': [round(v, 3) for v in per_step]}
     if precision == 'f32':      # the three GEMM families run on the exact-f32 MFMA: that pipe bounds the step
         out['roofline'] = {'bound': 'mfma', 'achieved': flop / dt / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': flop / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
