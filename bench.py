@@ -261,6 +261,20 @@ def attack_bench(dev, iters=5):
     out['end_to_end_victim_cnn_cached_original_logits'] = {
         'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
         'note': 'same, gauss_net.cache_ori_cla = True (1 classifier forward per step; identical results)'}
+    # NeRFail's per-view inner loop (deepfool.py:44-107): one view, 8 classes, untargeted (7 competing classes per
+    # iteration); m1 is set so that the loop never stops early
+    from nerfail_amd.deepfool import deepfool
+    net.cache_ori_cla = False
+    n_it = 6
+    deepfool((s_init, wi[:1], ori[:1]), 1.0, net, num_classes=8, max_iter=2, m1=1e6, m2=30)          # warm-up
+    torch.cuda.synchronize()
+    t = time.time()
+    _, loop_i, _, _, _ = deepfool((s_init, wi[:1], ori[:1]), 1.0, net, num_classes=8, max_iter=n_it, m1=1e6, m2=30)
+    torch.cuda.synchronize()
+    dt = (time.time() - t) / max(loop_i, 1)
+    out['deepfool_inner_loop'] = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
+                                  'note': 'one 800x800 view, 8 class gradients per iteration: victim CNN fwd + 8 bwd (stock '
+                                          'PyTorch) + one multi-RHS pass over the inverted index'}
     out['batch_views'] = B
     out['unit'] = 'NeRFail-S iterations/s (batch of 8 views, 800x800, P=3)'
     return out

@@ -248,6 +248,20 @@ int nerfail_gauss_bwd_csr_multi(const float* ori_img, const float* x, const floa
                                 int64_t B, int64_t P, float epsilon, float* pixel_grad_scratch, float* grad_spatial,
                                 void* stream);
 
+/* K14 - DeepFool step arithmetic over the perturbation table (deepfool.py:76-102). grads = [n_rhs][n,4] as written by
+ * nerfail_gauss_bwd_csr_multi, slice 0 = original class.
+ *   norms:  norms2[k-1] = ||grads[k] - grads[0]||^2 (torch.norm(grad_prime)**2), k = 1..n_rhs-1; two-stage reduction with a
+ *           fixed tree (bitwise reproducible); scratch: nerfail_deepfool_norms_scratch_bytes() bytes.
+ *   apply:  rot += scale[0] * (grads[best[0]] - grads[0]) (skipped when scale[0] == 0);
+ *           spatial_out = clamp(spatial_init + overshoot * rot, -255, 255), alpha channel copied from spatial_init.
+ *           best (int32, 1..n_rhs-1) and scale are DEVICE scalars: no host round trip between choosing the class and
+ *           applying it. rot is updated in place; spatial_out may alias nothing else. */
+size_t nerfail_deepfool_norms_scratch_bytes(int n_rhs, int64_t n);
+int nerfail_deepfool_norms(const float* grads, int n_rhs, int64_t n, void* scratch, size_t scratch_bytes, float* norms2,
+                           void* stream);
+int nerfail_deepfool_apply(const float* grads, int n_rhs, int64_t n, const int32_t* best, const float* scale,
+                           float overshoot, const float* spatial_init, float* rot, float* spatial_out, void* stream);
+
 /* NeRFail-S sign step, AS:352-392: rgb <- rgb -/+ a*sign(grad) where alpha > 0 else 0, clamped to
  * init +- epsilon; alpha channel copied. spatial/grad/spatial_init/out are [n,4]; out may alias spatial. */
 int nerfail_igsm_step(const float* spatial, const float* grad, const float* spatial_init, int64_t n,

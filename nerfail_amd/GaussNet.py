@@ -234,7 +234,8 @@ class gauss_net(nn.Module):
         out = torch.empty((C, n, 4), dtype=torch.float32, device=J.device)
         scratch = torch.empty((C * B * P, 4), dtype=torch.float32, device=J.device)
         eps = -1.0 if self.epsilon is None else float(self.epsilon)
-        _lib.check(_lib.load().nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(_lib.f32c(x)), _lib.dev(J), C,
+        x_c = _lib.f32c(x)            # bound to a name: see deepfool.py on pointers of temporaries
+        _lib.check(_lib.load().nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(x_c), _lib.dev(J), C,
                                                            _lib.dev(csr.row_ptr), _lib.dev(csr.contrib), _lib.dev(csr.w_sorted),
                                                            n, B, P, eps, _lib.dev(scratch), _lib.dev(out), _lib.stream()))
         return out.reshape((C,) + tuple(spatial_rgb.shape))

@@ -77,6 +77,9 @@ SIGNATURES = {
     'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
     'nerfail_gauss_bwd_csr_multi': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
+    'nerfail_deepfool_norms_scratch_bytes': (ctypes.c_size_t, [c_i, c_i64]),
+    'nerfail_deepfool_norms': (c_i, [c_p, c_i, c_i64, c_p, ctypes.c_size_t, c_p, c_p]),
+    'nerfail_deepfool_apply': (c_i, [c_p, c_i, c_i64, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_igsm_step': (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p]),
     'nerfail_adam_step': (c_i, [c_p, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_p]),
 }

@@ -13,6 +13,8 @@ competing class is then chosen on the device (first minimum, NaN never chosen: d
 """
 import torch
 
+from . import _lib
+
 
 def _grad(out_scalar, wrt):
     return torch.autograd.grad(out_scalar, wrt, retain_graph=True, create_graph=False)[0]
@@ -55,27 +57,45 @@ def deepfool(net_input, e, net, num_classes=8, max_iter=20, target_label: int = 
             ks = [k for k in range(num_classes) if k != o]
         else:
             ks = [int(target_label)]
+        f_prime = (cla[0, ks] - (cla[0, o] + m2)).detach()                              # deepfool.py:79
         if multi:
+            # all class gradients in one pass over the inverted index (K11 multi-RHS), then the step arithmetic in two
+            # streaming kernels (K14): ||G_k - G_o||^2 for every k, device-side choice, rot / clamp / alpha restore
             G = net.logit_gradients(spatial_rgb, net._last_wi, x_out, x_rgba, cla, [o] + ks)
-            grad_o, grads_k = G[0], G[1:]
+            lib = _lib.load()
+            C, n = G.shape[0], G[0].numel() // 4
+            nb = lib.nerfail_deepfool_norms_scratch_bytes(C, n)
+            scratch = torch.empty((nb,), dtype=torch.uint8, device=G.device)
+            norms2 = torch.empty((C - 1,), dtype=torch.float32, device=G.device)
+            _lib.check(lib.nerfail_deepfool_norms(_lib.dev(G), C, n, _lib.dev(scratch), nb, _lib.dev(norms2), _lib.stream()))
+            nrm = torch.sqrt(norms2)                                                    # torch.norm(grad_prime), every k
         else:
             grad_o = _grad(cla[:, o].sum(), spatial_rgb)
             grads_k = torch.stack([_grad(cla[:, k].sum(), spatial_rgb) for k in ks])
-        grad_prime = grads_k - grad_o.unsqueeze(0)                                      # deepfool.py:78 for every k
-        f_prime = (cla[0, ks] - (cla[0, o] + m2)).detach()                              # deepfool.py:79
-        nrm = torch.linalg.vector_norm(grad_prime.reshape(len(ks), -1), dim=1)          # torch.norm(grad_prime)
+            grad_prime = grads_k - grad_o.unsqueeze(0)                                  # deepfool.py:78 for every k
+            nrm = torch.linalg.vector_norm(grad_prime.reshape(len(ks), -1), dim=1)
         if target_label is None:
             value_r = torch.abs(f_prime) / (nrm + 0.0001)                               # deepfool.py:81
             value_r = torch.where(torch.isnan(value_r), torch.full_like(value_r, float('inf')), value_r)
             best = torch.argmin(value_r)                                                # first minimum = strict `<` scan
             scale = torch.abs(f_prime[best]) / ((nrm[best] ** 2) + 0.0001)              # deepfool.py:86
-            dr = torch.where(torch.isinf(value_r[best]), torch.zeros_like(grad_prime[0]), scale * grad_prime[best])
+            scale = torch.where(torch.isinf(value_r[best]), torch.zeros_like(scale), scale)   # nothing chosen: dr = 0
         else:
-            dr = (torch.abs(f_prime[0]) / ((nrm[0] ** 2) + 0.0001)) * grad_prime[0]      # deepfool.py:92-96
-
-        rot = (rot + dr).detach()
-        spatial_rgb = torch.clamp((spatial_rgb_0 + (overshoot * rot)).detach(), -255, 255)
-        spatial_rgb = torch.cat([spatial_rgb[:, :, :, :3], spatial_rgb_0[:, :, :, 3].unsqueeze(-1)], -1)   # alpha unchanged
+            best = torch.zeros((), dtype=torch.int64, device=nrm.device)
+            scale = torch.abs(f_prime[0]) / ((nrm[0] ** 2) + 0.0001)                    # deepfool.py:92-96
+        if multi:
+            rot = _lib.f32c(rot)
+            new_s = torch.empty_like(spatial_rgb_0)
+            # the device scalars are bound to names: a temporary freed right after its pointer was taken could be handed
+            # to the next allocation and overwritten before the kernel (enqueued afterwards) reads it
+            best_i, scale_f, s0_c = (best + 1).to(torch.int32), scale.to(torch.float32).reshape(1), _lib.f32c(spatial_rgb_0)
+            _lib.check(lib.nerfail_deepfool_apply(_lib.dev(G), C, n, _lib.dev(best_i), _lib.dev(scale_f), float(overshoot),
+                                                  _lib.dev(s0_c), _lib.dev(rot), _lib.dev(new_s), _lib.stream()))
+            spatial_rgb = new_s                                                         # deepfool.py:98-102 fused
+        else:
+            rot = (rot + scale * grad_prime[best]).detach()
+            spatial_rgb = torch.clamp((spatial_rgb_0 + (overshoot * rot)).detach(), -255, 255)
+            spatial_rgb = torch.cat([spatial_rgb[:, :, :, :3], spatial_rgb_0[:, :, :, 3].unsqueeze(-1)], -1)   # alpha unchanged
         loop_i += 1
 
     spatial_rgb = spatial_rgb.detach()

@@ -89,3 +89,45 @@ def test_logit_gradients_match_autograd():
     for i, k in enumerate(classes):
         ref = torch.autograd.grad(cla[0, k], st, retain_graph=True)[0]
         assert rel_err(N(G[i]), N(ref)) < 1e-6, k
+
+
+def test_deepfool_step_kernels():
+    """K14 (nerfail_deepfool_norms / nerfail_deepfool_apply) against numpy: squared norms of the gradient differences
+    (float64 reference, fixed-tree reduction => repeatable bits), the fused rot / clamp / alpha-restore update exactly."""
+    from nerfail_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(14)
+    for C, n in ((8, 3 * 37 * 41), (2, 5), (5, 70000)):
+        G = (rng.normal(size=(C, n, 4)) * rng.uniform(0.1, 30, size=(C, 1, 1))).astype(np.float32)
+        Gd = T(G)
+        nb = lib.nerfail_deepfool_norms_scratch_bytes(C, n)
+        assert nb > 0
+        scratch = torch.empty((nb,), dtype=torch.uint8, device=dev())
+        out = []
+        for _ in range(2):
+            norms2 = torch.empty((C - 1,), device=dev())
+            _lib.check(lib.nerfail_deepfool_norms(_lib.dev(Gd), C, n, _lib.dev(scratch), nb, _lib.dev(norms2), _lib.stream()))
+            out.append(N(norms2))
+        assert np.array_equal(out[0], out[1])
+        ref = ((G[1:].astype(np.float64) - G[0:1].astype(np.float64)) ** 2).reshape(C - 1, -1).sum(1)
+        assert np.all(np.abs(out[0] - ref) <= 2e-6 * ref)
+        s0 = rng.uniform(-300, 300, size=(n, 4)).astype(np.float32)
+        rot = rng.normal(size=(n, 4)).astype(np.float32)
+        k, sc, over = C - 1, np.float32(0.37), 0.02
+        rot_d, new_s = T(rot.copy()), torch.empty((n, 4), device=dev())
+        best_d, sc_d, s0_d = torch.tensor([k], dtype=torch.int32, device=dev()), torch.tensor([sc], device=dev()), T(s0)
+        _lib.check(lib.nerfail_deepfool_apply(_lib.dev(Gd), C, n, _lib.dev(best_d), _lib.dev(sc_d), over, _lib.dev(s0_d),
+                                              _lib.dev(rot_d), _lib.dev(new_s), _lib.stream()))
+        rot_ref = rot + sc * (G[k] - G[0])
+        s_ref = np.clip(s0 + np.float32(over) * rot_ref, -255, 255).astype(np.float32)
+        s_ref[:, 3] = s0[:, 3]
+        assert np.array_equal(N(rot_d), rot_ref) and np.array_equal(N(new_s), s_ref)
+        # scale 0 = nothing chosen: rot untouched even if the gradients hold inf
+        Gbad = Gd.clone()
+        Gbad[k, 0, 0] = float('inf')
+        rot_d, zero_d = T(rot.copy()), torch.zeros(1, device=dev())
+        _lib.check(lib.nerfail_deepfool_apply(_lib.dev(Gbad), C, n, _lib.dev(best_d), _lib.dev(zero_d), over, _lib.dev(s0_d),
+                                              _lib.dev(rot_d), _lib.dev(new_s), _lib.stream()))
+        assert np.array_equal(N(rot_d), rot)
+    assert lib.nerfail_deepfool_norms_scratch_bytes(1, 10) == 0 and lib.nerfail_deepfool_norms_scratch_bytes(9, 10) == 0
+    assert lib.nerfail_deepfool_norms(_lib.dev(Gd), 5, 70000, _lib.dev(scratch), 8, _lib.dev(norms2), _lib.stream()) != 0
