@@ -627,6 +627,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_lds_kernel(LArgs 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long total = a.cum[a.ngroups];
+    const unsigned long long nf_w0 = (NF_DW_ABLATE == 9) ? wall_clock64() : 0;
     const long lo = total / gridDim.x * blockIdx.x + (total % gridDim.x) * blockIdx.x / gridDim.x;
     const long hi = total / gridDim.x * (blockIdx.x + 1) + (total % gridDim.x) * (blockIdx.x + 1) / gridDim.x;
     for (int g = 0; g < a.ngroups; ++g) {
@@ -646,6 +647,8 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_lds_kernel(LArgs 
             default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
         }
     }
+    if (NF_DW_ABLATE == 9 && threadIdx.x == 0)      // timing probe: this workgroup's busy time in 10 ns ticks, over dz[0..]
+        reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;
 }
 
 static int cu_count() {
@@ -797,12 +800,11 @@ static int bwd_weights_impl(int D, int W, int skip, const float* acts, const flo
         part(d, TL.a_H1 + (D - 1) * NT, NT, 0, 0, W);
     }
     a.ndesc = nd;
-    // Kernel choice (W = 256): exact-f32 weight gradients run on the LDS-staged kernel (MFMA bound, the staging keeps the
-    // pipe fed), the bf16x3 form on the register-fed kernel (both forms of it move the same 4.3 GB per 196 608 samples
-    // and sit at the ~4 TB/s this access pattern gets from HBM: 1.12 vs 1.21 ms; without its loads the LDS kernel
-    // needs 0.42 ms). NERFAIL_DW_KERNEL=reg | lds forces one for A/B timing and for the parity tests of both.
+    // Kernel choice: W = 256 runs on the LDS-staged kernel in both precisions (exact f32 2.41 -> 2.01 ms, bf16x3
+    // 1.12 -> 1.05 ms at 196 608 samples once its partition used fitted step costs); other widths and
+    // NERFAIL_DW_KERNEL=reg take the register-fed kernel (kept for A/B timing and parity-tested alongside).
     const char* dwk = getenv("NERFAIL_DW_KERNEL");
-    const bool use_lds = dwk != nullptr ? dwk[0] == 'l' : !bf16x3;
+    const bool use_lds = dwk != nullptr ? dwk[0] == 'l' : true;
     if (NT == 8 && use_lds) {   // LDS-staged kernel: one group per layer-part, in descriptor order
         LArgs la;
         la.acts = acts; la.dz = dz; la.ntiles = a.ntiles; la.a_slots = a.a_slots; la.z_slots = a.z_slots;
@@ -825,13 +827,18 @@ static int bwd_weights_impl(int D, int W, int skip, const float* acts, const flo
                 LGroup& g = la.grp[ng];
                 g.desc = di; g.part = p; g.dz_slot0 = d.dz_slot0; g.x_slot0 = d.parts[p].slot0; g.shape = shape;
                 const int G = (2 * (LA + LB) + 3) / 4;
-                la.cost[ng] = (bf16x3 ? 96 : 512) * ma * nb + 70 * G + 150;   // cycles per k16-step: 3 x 32 (bf16) or 8 x 64 (f32) per tile pair + staging
+                // ns per k16-step of each group shape, FITTED to per-workgroup busy times (tools/dw_balance.py): the
+                // obvious model (MFMA cycles + a staging constant) under-estimated the small shapes by 15-35 % and left
+                // the workgroups that own them 25-36 % over the mean
+                static const int kStepNs[2][6] = {{4444, 2467, 1489, 535, 535, 811}, {2023, 1435, 1092, 541, 536, 655}};
+                (void)ma; (void)nb; (void)G;
+                la.cost[ng] = kStepNs[bf16x3 ? 1 : 0][shape];
                 la.cum[ng + 1] = la.cum[ng] + (long)la.cost[ng] * la.ntiles;
                 ++ng;
             }
         la.ngroups = ng;
         long wgs = cu_count();
-        const long min_units = (bf16x3 ? 2246L : 8902L) * 4;       // at least ~4 full-layer tiles per workgroup
+        const long min_units = (bf16x3 ? 2023L : 4444L) * 4;       // at least ~4 full-layer tiles per workgroup
         if (wgs > la.cum[ng] / min_units) wgs = la.cum[ng] / min_units > 0 ? la.cum[ng] / min_units : 1;
         if (bf16x3) nerf_mlp_bwd_weights_lds_kernel<true><<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(la);
         else nerf_mlp_bwd_weights_lds_kernel<false><<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(la);
