@@ -528,31 +528,53 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
             if (NF_DW_ABLATE != 1) __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + pc * 256), 16, 0, NF_DW_AUX);
         }
     };
+    // Operands of a step are read from LDS into registers one step AHEAD (raw[..]), so the ds_read latency and the
+    // barrier hide behind the MFMAs of the previous step; a stage therefore has to land one step earlier.
+    f32x4 rawA[MA][2], rawB[NB][2];
+    auto fetch = [&](int rs) {                                          // LDS -> registers: this wave's MA + NB tiles of one stage
+        const float* __restrict__ st = smem + rs * kLdsStageFloats;
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+            rawA[m][0] = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd0);
+            rawA[m][1] = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd1);
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            rawB[n][0] = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd0);
+            rawB[n][1] = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd1);
+        }
+    };
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue(s, s);
-    int rs_read = 0, rs_issue = NS - 1;
+    wait_vmcnt<(NS - 2) * G>();                                         // stage 0 (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    fetch(0);
+    int rs_next = 1, rs_issue = NS - 1;
     for (long s = 0; s < S; ++s) {
-        wait_vmcnt<(NS - 2) * G>();                                     // this wave's pieces of stage s have landed
-        __builtin_amdgcn_s_barrier();                                   // ... everyone's have; and stage s-1 is no longer read
-        issue(s + NS - 1, rs_issue);
-        const float* __restrict__ st = smem + rs_read * kLdsStageFloats;
+        // operands of step s leave the raw registers (bf16: split into hi / lo)
+        u32x4b ah[BF16 ? MA : 1], al[BF16 ? MA : 1], bh[BF16 ? NB : 1], bl[BF16 ? NB : 1];
+        f32x4 av[BF16 ? 1 : MA][2], bv[BF16 ? 1 : NB][2];
+#pragma unroll
+        for (int m = 0; m < MA; ++m) {
+            if (do_bias) rowsum[m] += (rawA[m][0][0] + rawA[m][0][1]) + (rawA[m][0][2] + rawA[m][0][3]) +
+                                      (rawA[m][1][0] + rawA[m][1][1]) + (rawA[m][1][2] + rawA[m][1][3]);
+            if constexpr (BF16) {
+                if (NF_DW_ABLATE == 2) { ah[m] = __builtin_bit_cast(u32x4b, rawA[m][0]); al[m] = __builtin_bit_cast(u32x4b, rawA[m][1]); }
+                else split_bf16(rawA[m][0], rawA[m][1], ah[m], al[m]);
+            } else { av[m][0] = rawA[m][0]; av[m][1] = rawA[m][1]; }
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            if constexpr (BF16) {
+                if (NF_DW_ABLATE == 2) { bh[n] = __builtin_bit_cast(u32x4b, rawB[n][0]); bl[n] = __builtin_bit_cast(u32x4b, rawB[n][1]); }
+                else split_bf16(rawB[n][0], rawB[n][1], bh[n], bl[n]);
+            } else { bv[n][0] = rawB[n][0]; bv[n][1] = rawB[n][1]; }
+        }
+        wait_vmcnt<(NS - 3) * G>();                                     // this wave's pieces of stage s+1 have landed
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's have; stage s is in everybody's registers
+        issue(s + NS - 1, rs_issue);                                    // into the slot stage s-1 occupied
+        fetch(rs_next);                                                 // stage s+1 (past the end: a harmless re-read)
         if constexpr (BF16) {
-            u32x4b ah[MA], al[MA], bh[NB], bl[NB];
-#pragma unroll
-            for (int m = 0; m < MA; ++m) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd0);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd1);
-                if (NF_DW_ABLATE == 2) { ah[m] = __builtin_bit_cast(u32x4b, v0); al[m] = __builtin_bit_cast(u32x4b, v1); }
-                else split_bf16(v0, v1, ah[m], al[m]);
-                if (do_bias) rowsum[m] += (v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3]);
-            }
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd0);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd1);
-                if (NF_DW_ABLATE == 2) { bh[n] = __builtin_bit_cast(u32x4b, v0); bl[n] = __builtin_bit_cast(u32x4b, v1); }
-                else split_bf16(v0, v1, bh[n], bl[n]);
-            }
 #pragma unroll
             for (int x = 0; x < 3; ++x)
 #pragma unroll
@@ -567,19 +589,6 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
         } else {
             // exact-f32 form: the 8 samples a lane holds are 8 k-steps of v_mfma_f32_32x32x2_f32 (k = (step, kh) <-> sample
             // 8*kh + step inside the k16-step: any bijection works as long as A and B use the same one)
-            f32x4 av[MA][2], bv[NB][2];
-#pragma unroll
-            for (int m = 0; m < MA; ++m) {
-                av[m][0] = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd0);
-                av[m][1] = *reinterpret_cast<const f32x4*>(st + (a0 + m) * 512 + rd1);
-                if (do_bias) rowsum[m] += (av[m][0][0] + av[m][0][1]) + (av[m][0][2] + av[m][0][3]) +
-                                          (av[m][1][0] + av[m][1][1]) + (av[m][1][2] + av[m][1][3]);
-            }
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                bv[n][0] = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd0);
-                bv[n][1] = *reinterpret_cast<const f32x4*>(st + (LA + b0 + n) * 512 + rd1);
-            }
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
@@ -588,7 +597,7 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
                     for (int n = 0; n < NB; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e >> 2][e & 3], bv[n][e >> 2][e & 3], acc[m][n], 0, 0, 0);
         }
-        rs_read = (rs_read + 1) & (NS - 1);
+        rs_next = (rs_next + 1) & (NS - 1);
         rs_issue = (rs_issue + 1) & (NS - 1);
     }
     wait_vmcnt<0>();                                                    // drain the padding stages before the ring is reused
@@ -830,7 +839,7 @@ static int bwd_weights_impl(int D, int W, int skip, const float* acts, const flo
                 // ns per k16-step of each group shape, FITTED to per-workgroup busy times (tools/dw_balance.py): the
                 // obvious model (MFMA cycles + a staging constant) under-estimated the small shapes by 15-35 % and left
                 // the workgroups that own them 25-36 % over the mean
-                static const int kStepNs[2][6] = {{4444, 2467, 1489, 535, 535, 811}, {2023, 1435, 1092, 541, 536, 655}};
+                static const int kStepNs[2][6] = {{4460, 2450, 1486, 496, 483, 732}, {2030, 1427, 987, 551, 539, 648}};
                 (void)ma; (void)nb; (void)G;
                 la.cost[ng] = kStepNs[bf16x3 ? 1 : 0][shape];
                 la.cum[ng + 1] = la.cum[ng] + (long)la.cost[ng] * la.ntiles;

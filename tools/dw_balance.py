@@ -35,6 +35,7 @@ for bf16 in (0, 1):
           ('bf16x3' if bf16 else 'f32', t.min(), t.mean(), t.max(), order[-4:], order[:4]))
 
 # ---- fit the per-step cost of each group shape from the per-workgroup times (least squares)
+K_STEP_NS = [[4460, 2450, 1486, 496, 483, 732], [2030, 1427, 987, 551, 539, 648]]   # copy of kStepNs (mlp_bwd.hip)
 def partition(bf16):
     NT, D = 8, 8
     groups = []      # (shape, ma*nb, G)
@@ -53,7 +54,7 @@ def partition(bf16):
     add(1, 4)            # rgb
     add(1, 8)            # alpha
     ntiles = R * N // 32
-    cost = [(96 if bf16 else 512) * mn + 70 * G + 150 for _, mn, G in groups]
+    cost = [K_STEP_NS[1 if bf16 else 0][sh] for sh, _, _ in groups]          # must mirror kStepNs in mlp_bwd.hip
     cum = np.concatenate([[0], np.cumsum([c * ntiles for c in cost])])
     total, W = cum[-1], 256
     A = np.zeros((W, 7))
@@ -87,4 +88,4 @@ for bf16 in (0, 1):
     A = partition(bf16)
     x, *_ = np.linalg.lstsq(A, t, rcond=None)
     print('bf16x3' if bf16 else 'f32', 'fitted ns per k16-step by shape [full, views, emb, dir, rgb, alpha], per flush:', np.round(x, 1),
-          ' model now (cycles):', [(96 if bf16 else 512) * mn + 70 * G + 150 for mn, G in ((16, 8), (8, 6), (4, 5), (1, 3), (1, 3), (2, 5))])
+          ' table now:', K_STEP_NS[1 if bf16 else 0])
