@@ -100,10 +100,69 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __r
 #ifndef NF_ROW_UNROLL
 #define NF_ROW_UNROLL 32
 #endif
+#ifndef NF_ROW_ABLATE
+#define NF_ROW_ABLATE 0     // timing experiments: 1 no gathers, 2 no output store, 3 no LDS staging (direct loads)
+#endif
 #ifndef NF_ROW_CAP
 #define NF_ROW_CAP 2048
 #endif
 constexpr int kRowCap = NF_ROW_CAP;    // index entries staged per wave (8 B each in LDS); longer ranges take the direct path
+
+constexpr int kLongRow = 256;     // rows longer than this are reduced by the whole wave
+
+// One long row, all 64 lanes: lane l takes entries l, l+64, ... (coalesced index / weight loads, 64 gathers in flight),
+// each chunk of 64 products is summed by a fixed butterfly, chunks are added in order: deterministic, and the same
+// order in the single- and the multi-RHS kernel. Every lane returns the total.
+template <int C>
+__device__ __forceinline__ void long_row(const int* __restrict__ contrib, const float* __restrict__ w_sorted,
+                                         const float4* __restrict__ g_pix, int c0, int len, int lane, float4 (&tot)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) tot[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < len; k += 64) {
+        const int i = k + lane;
+        const bool ok = i < len;
+        const int ci = c0 + (ok ? i : 0);
+        const int id = contrib[ci];
+        const float w = ok ? w_sorted[ci] : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 g = g_pix[(long)(id >> 3) * C + c];
+            float4 p = ok ? make_float4(w * g.x, w * g.y, w * g.z, w * g.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64);
+                p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
+            }
+            tot[c].x += p.x; tot[c].y += p.y; tot[c].z += p.z; tot[c].w += p.w;
+        }
+    }
+}
+
+// Copies the wave's contiguous index / weight range into LDS. 8 coalesced load pairs are issued before the first is
+// consumed (clamped addresses, so every load is unconditional): with one pair per loop iteration the ~21 iterations of
+// a wave were a chain of exposed memory round trips - most of the kernel's time.
+__device__ __forceinline__ void stage_rows(int* __restrict__ sid, float* __restrict__ sw, const int* __restrict__ contrib,
+                                           const float* __restrict__ w_sorted, int n, int lane) {
+    constexpr int U = 8;
+    for (int i0 = 0; i0 < n; i0 += 64 * U) {
+        int id[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 64 + lane;
+            const int ic = i < n ? i : n - 1;
+            id[u] = contrib[ic];
+            w[u] = w_sorted[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 64 + lane;
+            if (i < n) { sid[i] = id[u]; sw[i] = w[u]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes before its reads
+}
 
 __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __restrict__ row_ptr, const int* __restrict__ contrib,
                                                                const float* __restrict__ w_sorted,
@@ -115,9 +174,15 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __rest
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long j0 = j - lane;                      // first row of this wave
     if (j0 >= Ns) return;                          // whole wave out of range
+    const unsigned long long nf_t0 = (NF_ROW_ABLATE == 9) ? wall_clock64() : 0;
     const long jc = j < Ns ? j : Ns - 1;
     const int c0 = row_ptr[jc];
-    const int len = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
+    const int len_raw = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
+    // A row far longer than the typical ~21 entries (a point that is the neighbour of thousands of pixels) would keep
+    // its one lane - and so the whole kernel - busy long after everything else has finished: such rows are left out of
+    // the lane-per-row walk and reduced afterwards by all 64 lanes together (long_row()).
+    const bool is_long = len_raw > kLongRow;
+    const int len = is_long ? 0 : len_raw;
     const int base = __shfl(c0, 0, 64);
     const long jl = (j0 + 64 < Ns) ? j0 + 64 : Ns;
     const int n = row_ptr[jl] - base;              // entries of the wave's 64 rows (wave-uniform)
@@ -125,12 +190,10 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __rest
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool staged = n <= kRowCap;
-    if (staged) {
-        for (int i = lane; i < n; i += 64) { s_id[wv][i] = contrib[base + i]; s_w[wv][i] = w_sorted[base + i]; }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes before its reads
-    }
+    const unsigned long long nf_t1 = (NF_ROW_ABLATE == 9) ? wall_clock64() + (unsigned long long)(maxlen & 0) : 0;
+    const bool staged = n <= kRowCap && NF_ROW_ABLATE != 3;
+    if (staged) stage_rows(s_id[wv], s_w[wv], contrib + base, w_sorted + base, n, lane);
+    const unsigned long long nf_t2 = (NF_ROW_ABLATE == 9) ? wall_clock64() + (unsigned long long)(s_id[wv][0] & 0) : 0;
     const int r0 = c0 - base;
     constexpr int U = NF_ROW_UNROLL;               // gathers in flight per lane and iteration
     for (int k = 0; k < maxlen; k += U) {
@@ -146,7 +209,7 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __rest
         }
         float4 g[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) g[u] = g_pix[id[u] >> 3];
+        for (int u = 0; u < U; ++u) g[u] = (NF_ROW_ABLATE == 1) ? make_float4(w[u], 1.f, 2.f, (float)id[u]) : g_pix[id[u] >> 3];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (k + u < len) {                     // keeps 0 * inf / NaN of a foreign row out of the sum
@@ -154,7 +217,18 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __rest
             }
         }
     }
-    if (j >= Ns) return;
+    for (unsigned long long lm = __ballot(is_long); lm != 0; lm &= lm - 1) {     // wave-uniform: the long rows of this wave
+        const int src = __ffsll((long long)lm) - 1;
+        float4 tot[1];
+        long_row<1>(contrib, w_sorted, g_pix, __shfl(c0, src, 64), __shfl(len_raw, src, 64), lane, tot);
+        if (lane == src) acc = tot[0];
+    }
+    if (NF_ROW_ABLATE == 9) {     // phase probe: ticks (10 ns) of header / staging / row walk, written instead of the result
+        const unsigned long long nf_t3 = wall_clock64() + (unsigned long long)(__float_as_uint(acc.x) & 0u);
+        if (j < Ns) grad_spatial[j] = make_float4((float)(nf_t1 - nf_t0), (float)(nf_t2 - nf_t1), (float)(nf_t3 - nf_t2), (float)n);
+        return;
+    }
+    if (j >= Ns || (NF_ROW_ABLATE == 2 && acc.x != 123.456f)) return;
     if (accumulate) {
         const float4 old = grad_spatial[j];
         acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
@@ -214,7 +288,9 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_multi_kernel(const int* 
     if (j0 >= Ns) return;
     const long jc = j < Ns ? j : Ns - 1;
     const int c0 = row_ptr[jc];
-    const int len = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
+    const int len_raw = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
+    const bool is_long = len_raw > kLongRow;       // see gauss_row_reduce_kernel
+    const int len = is_long ? 0 : len_raw;
     const int base = __shfl(c0, 0, 64);
     const long jl = (j0 + 64 < Ns) ? j0 + 64 : Ns;
     const int n = row_ptr[jl] - base;
@@ -225,11 +301,7 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_multi_kernel(const int* 
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool staged = n <= kRowCap;
-    if (staged) {
-        for (int i = lane; i < n; i += 64) { s_id[wv][i] = contrib[base + i]; s_w[wv][i] = w_sorted[base + i]; }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    }
+    if (staged) stage_rows(s_id[wv], s_w[wv], contrib + base, w_sorted + base, n, lane);
     const int r0 = c0 - base;
     constexpr int U = 4;
     for (int k = 0; k < maxlen; k += U) {          // same contribution order per row as the single-RHS kernel => same bits
@@ -257,6 +329,15 @@ __global__ __launch_bounds__(256) void gauss_row_reduce_multi_kernel(const int* 
                     acc[c].z += w[u] * g[u][c].z; acc[c].w += w[u] * g[u][c].w;
                 }
             }
+        }
+    }
+    for (unsigned long long lm = __ballot(is_long); lm != 0; lm &= lm - 1) {
+        const int src = __ffsll((long long)lm) - 1;
+        float4 tot[C];
+        long_row<C>(contrib, w_sorted, g_pix, __shfl(c0, src, 64), __shfl(len_raw, src, 64), lane, tot);
+        if (lane == src) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = tot[c];
         }
     }
     if (j >= Ns) return;

@@ -142,3 +142,51 @@ def test_cached_original_logits_are_identical():
     calls.clear()
     c = net(s, wi, ori)
     assert len(calls) == 2 and not torch.equal(c[4], ref[4])
+
+
+def test_backward_with_very_long_rows():
+    """A perturbation row that is the neighbour of thousands of pixels (kLongRow = 256 in gauss_csr.hip) takes the
+    cooperative whole-wave path of the inverted-index backward: result vs the oracle, bitwise repeatable, and the
+    multi-RHS kernel still bitwise equal to the single one."""
+    from nerfail_amd import _lib
+    from nerfail_amd.GaussNet import gauss_gather, create_gauss_w, csr_for
+    rs = np.random.RandomState(21)
+    P, B, H, W = 2, 2, 40, 36
+    Ns = P * H * W
+    s = rs.uniform(-30, 30, (P, H, W, 4)).astype(np.float32)
+    s[..., 3] = 255.0
+    ori = synth.disc_alpha_image(B, H, W, seed=5)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, Ns, (B, H, W, 8))
+    hot = rs.uniform(size=idx.shape)
+    idx[hot < 0.25] = 7                       # ~5 800 contributions to row 7
+    idx[(hot >= 0.25) & (hot < 0.30)] = Ns - 1    # ~1 100 to the last row
+    idx[(hot >= 0.30) & (hot < 0.32)] = 1000      # ~460 to a row in the middle
+    wi_np, _ = OG.create_gauss_w(np.stack([dist, idx.astype(np.float32)], 1))
+    G = rs.normal(size=(B, H, W, 4)).astype(np.float32)
+    wi, oriT = T(wi_np), T(ori)
+    grads = []
+    for _ in range(2):
+        st = T(s).requires_grad_(True)
+        x, xr = gauss_gather(st, wi, oriT, 32.0, None, True)
+        (xr * T(G)).sum().backward()
+        grads.append(N(st.grad))
+    assert np.array_equal(grads[0], grads[1])
+    ref = OG.gauss_backward(s, wi_np, ori, np.zeros_like(G), G, 32.0)
+    assert np.abs(grads[0] - ref).max() <= 2e-5 * np.abs(ref).max()
+    # multi-RHS: slice c of one launch == a single launch with that right-hand side
+    lib = _lib.load()
+    n, Pp = Ns, H * W
+    csr = csr_for(wi, n)
+    J = T(rs.normal(size=(3, B * Pp, 4)).astype(np.float32))
+    out = torch.empty((3, n, 4), device=dev())
+    scratch = torch.empty((3 * B * Pp, 4), device=dev())
+    st = T(s).requires_grad_(True)
+    x, xr = gauss_gather(st, wi, oriT, 32.0, None, True)
+    xs = x.detach()
+    _lib.check(lib.nerfail_gauss_bwd_csr_multi(_lib.dev(oriT), _lib.dev(xs), _lib.dev(J), 3, _lib.dev(csr.row_ptr),
+                                               _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), n, B, Pp, 32.0,
+                                               _lib.dev(scratch), _lib.dev(out), _lib.stream()))
+    for c in range(3):
+        single = torch.autograd.grad(xr, st, grad_outputs=J[c].reshape(xr.shape), retain_graph=True)[0]
+        assert torch.equal(out[c].reshape(single.shape), single), c
