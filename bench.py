@@ -350,6 +350,17 @@ def main():
         mlp_events.append((e0, e1, pts.shape[0] * pts.shape[1]))
         return out
     RN._mlp_points = timed_mlp
+    comp_events = []
+    orig_comp = RN._composite
+
+    def timed_composite(raw, z_vals, rays, noise, white_bkgd, pts=None):   # the compositing scan (K5), same event scheme
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_comp(raw, z_vals, rays, noise, white_bkgd, pts)
+        e1.record()
+        comp_events.append((e0, e1, z_vals.shape[0] * (24 * z_vals.shape[1] + 36)))     # 24N + 36 B per ray
+        return out
+    RN._composite = timed_composite
 
     def step(i):
         c2w = synth.pose_spherical(float(thetas[(i * world + rank) % len(thetas)]), -30., 4.)[:3, :4]
@@ -365,6 +376,7 @@ def main():
             step(i)
     barrier()
     mlp_events.clear()
+    comp_events.clear()
     t0 = time.time()
     for i in range(args.steps):
         with torch.no_grad():                      # render-only, as nerf_to_coord.py:619 does
@@ -386,6 +398,8 @@ def main():
         traffic = k['fetch_bytes_per_launch_corrected'] + k['write_bytes_per_launch']
     except Exception:
         pass
+    comp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in comp_events)
+    comp_bytes = sum(b for _, _, b in comp_events)
     mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in mlp_events)
     mlp_samples = sum(n for _, _, n in mlp_events)
     achieved = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
@@ -406,6 +420,11 @@ def main():
                          'traffic': traffic, 'traffic_unit': 'HBM+IC bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                          'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
                          'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
+            # the other roofline the north star asks for: achieved HBM rate of the compositing scan (K5 + K7)
+            'composite_scan': {'bound': 'hbm', 'kernel': 'composite_kernel<1|3>', 'achieved': comp_bytes / max(comp_ms, 1e-9) / 1e6,
+                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': comp_bytes / max(comp_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
+                               'launches': len(comp_events), 'ms_total': comp_ms,
+                               'note': 'algorithmic 24N+36 B per ray (coarse N=64 and fine N=192 launches together)'},
         }
         if not args.no_attack and world == 1:
             if 'train' in sections:
