@@ -206,7 +206,7 @@ static int grid_dim_for(long n) {
 
 static size_t knn_cub_temp(long n) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                                        (int*)nullptr, (int)n, 0, 32, (hipStream_t) nullptr);
     return bytes;
 }
