@@ -140,6 +140,8 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __rest
 // spills in the loop: the limit is delivery rate, not latency) and lock-stepping the 4 waves with one s_barrier per
 // quad so that one L2 fetch serves all four from L1 (17.9 ms: a barrier couples every wave to the slowest one; one
 // barrier per layer: 16.2 ms - aligned waves miss L1 together, free-running ones already share it by drifting).
+// Tried against the layer-boundary shuffles: a two-layer loop body in which the two register arrays swap roles
+// (no copies, in-place ReLU): no change for inference (14.15 ms), 6 % slower with the training stores.
 template <int OT, int NQ, int PFQ = NF_MLP_PF, typename BSel>
 __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __restrict__ w, int lane, BSel bsel) {
     const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
