@@ -157,6 +157,7 @@ __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __rest
 #pragma unroll
             for (int t = 0; t < OT; ++t)
                 ring[(q + PF) % RING][t] = (NF_FWD_ABLATE == 4) ? (f32x4){ring[q % RING][t][1], ring[q % RING][t][2], ring[q % RING][t][3], ring[q % RING][t][0]}
+                                                                : (NF_FWD_ABLATE == 6) ? __builtin_nontemporal_load(&wp[((q + PF) * OT + t) * 64])
                                                                 : wp[(((NF_FWD_ABLATE == 5) ? (q & 1) : (q + PF)) * OT + t) * 64];
             // Pin the software pipeline: nothing may be scheduled across this point, so the loads of quad q+PF stay
             // AHEAD of the 4*OT MFMAs of quad q (under register pressure the scheduler otherwise sinks them next to
