@@ -122,6 +122,31 @@ __device__ __forceinline__ void top8_insert_lex(Top8L& t, float d2, int idx) {
     if (key_less(d2, idx, t.d[0], t.i[0])) { t.d[0] = d2; t.i[0] = idx; }
 }
 
+#ifndef NF_KNN_BATCH
+#define NF_KNN_BATCH 8     // 1 (one load per candidate): 1.84 ms per 640 000-query view, 2: 1.61, 4: 1.37, 8: 1.27, 16: 1.33
+#endif
+// Candidates [b, e) of one contiguous cell range against the running top-8. NF_KNN_BATCH point loads are issued before the first
+// is examined (clamped index, so the loads are unconditional): the search is latency bound, one dependent 16-byte load
+// per candidate otherwise. The order in which candidates are examined does not matter: the key (d2, index) is total.
+__device__ __forceinline__ void scan_points(const float4* __restrict__ sorted, int b, int e, float qx, float qy, float qz,
+                                            Top8L& top) {
+    constexpr int U = NF_KNN_BATCH;
+    for (int p = b; p < e; p += U) {
+        float4 pt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pt[u] = sorted[min(p + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u < e) {
+                const float dx = __fsub_rn(qx, pt[u].x), dy = __fsub_rn(qy, pt[u].y), dz = __fsub_rn(qz, pt[u].z);
+                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                const int id = __float_as_int(pt[u].w);
+                if (key_less(d2, id, top.d[7], top.i[7])) top8_insert_lex(top, d2, id);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict__ queries, long nq, const Grid* __restrict__ gp,
                                                         const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                                         float* __restrict__ dist, float* __restrict__ idx_f,
@@ -148,27 +173,13 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
                 // otherwise only the two end cells x = cx -+ R do
                 const long row = ((long)z * G + y) * G;
                 if (yface) {
-                    const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
-                    for (int p = b; p < e; ++p) {
-                        const float4 pt = sorted[p];
-                        const float dx = __fsub_rn(qx, pt.x), dy = __fsub_rn(qy, pt.y), dz = __fsub_rn(qz, pt.z);
-                        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                        const int id = __float_as_int(pt.w);
-                        if (key_less(d2, id, top.d[7], top.i[7])) top8_insert_lex(top, d2, id);
-                    }
+                    scan_points(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, top);
                 } else {
 #pragma unroll
                     for (int side = 0; side < 2; ++side) {
                         const int x = side ? cx + R : cx - R;
                         if (x < 0 || x >= G || (side == 1 && R == 0)) continue;
-                        const int b = cell_start[row + x], e = cell_start[row + x + 1];
-                        for (int p = b; p < e; ++p) {
-                            const float4 pt = sorted[p];
-                            const float dx = __fsub_rn(qx, pt.x), dy = __fsub_rn(qy, pt.y), dz = __fsub_rn(qz, pt.z);
-                            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                            const int id = __float_as_int(pt.w);
-                            if (key_less(d2, id, top.d[7], top.i[7])) top8_insert_lex(top, d2, id);
-                        }
+                        scan_points(sorted, cell_start[row + x], cell_start[row + x + 1], qx, qy, qz, top);
                     }
                 }
             }
