@@ -113,14 +113,18 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     for i in range(steps):
         loss = step()
         marks[i + 1].record()
+        if i >= 1:
+            marks[i].synchronize()          # the host stays at most one step ahead of the GPU (see the note below)
     torch.cuda.synchronize()
     dt = (time.time() - t) / steps
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     evals = n_rand * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)                           # coarse + fine network evaluations
     flop = evals * FLOP_PER_SAMPLE * 3                                                # fwd + bwd-data + bwd-weights
-    # The shared GPU boxes show sporadic 30-110 ms stalls in host-driven sections (seen in any section, more often right
-    # after another process exited). The section's rate is therefore the MEDIAN step; the mean over the whole timed
-    # loop and every step's time are reported next to it.
+    # On the shared GPU boxes single training steps (mostly of the exact-f32 section) sporadically take 30-110 ms instead
+    # of 8, most reliably in the first section of a process started right after another GPU process exited, sometimes
+    # as a 34 / 60 / 110 ms ramp at the end of a section. The kernels are the same ones as in the fast steps and bounding
+    # the host's run-ahead (above) does not remove it: it looks like clock / power management, not like this code. The
+    # section's rate is therefore the MEDIAN step; the whole-loop mean and every step's time are reported next to it.
     mean_dt = dt
     dt = float(np.median(per_step)) * 1e-3
     out = {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand, 'precision': precision,
