@@ -44,6 +44,14 @@ def test_argument_validation_without_gpu():
     assert lib.nerfail_mlp_packed_T_floats(8, 256, 4) == 9 * 32 * 8 * 256 - 16 * 8 * 256    # 8 full layers + views (half the quads)
     # per 32-sample tile: E0 E1 V + 8 layers and feature x 8 slots + 4 hv slots + 3 slots of ReLU bit masks
     assert lib.nerfail_mlp_train_acts_floats(8, 256, 64) == 2 * (3 + 9 * 8 + 4 + 3) * 1024
+    # multi-RHS gauss backward and the DeepFool step kernels: sizes and NULL pointers are rejected before any launch
+    assert lib.nerfail_gauss_bwd_csr_multi(None, None, None, 8, None, None, None, 10, 1, 10, -1.0, None, None, None) == 1
+    assert lib.nerfail_deepfool_norms_scratch_bytes(8, 1000) == ((1000 + 2047) // 2048) * 7 * 8
+    assert lib.nerfail_deepfool_norms_scratch_bytes(1, 1000) == 0 and lib.nerfail_deepfool_norms_scratch_bytes(9, 1000) == 0
+    assert lib.nerfail_deepfool_norms(None, 8, 1000, None, 0, None, None) == 1
+    assert lib.nerfail_deepfool_norms(None, 1, 1000, None, 0, None, None) == 1
+    assert lib.nerfail_deepfool_apply(None, 8, 1000, None, None, 0.02, None, None, None, None) == 1
+    assert lib.nerfail_deepfool_apply(None, 8, 0, None, None, 0.02, None, None, None, None) == 1
     # optimizer step: nothing to do / NULL table / NULL tensor pointers are rejected before any launch
     assert lib.nerfail_adam_step(None, 0, 0.9, 0.999, 1e-8, None) == 0
     assert lib.nerfail_adam_step(None, 2, 0.9, 0.999, 1e-8, None) == 1
