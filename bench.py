@@ -20,9 +20,31 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+
+def _usable_cpus():
+    """CPUs this process may actually use: the cgroup quota (cpu.max) if there is one, else the affinity mask."""
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+# The GPU boxes report 256 CPUs but grant a 16-CPU cgroup quota. OpenMP / OpenBLAS pools sized for 256 then spin through
+# the quota and CFS throttles the whole process in 100 ms periods - seen as training steps of 30-110 ms instead of 8
+# (the launch thread simply did not run). Size the pools to what the process may use, BEFORE numpy / torch create them.
+N_CPU = _usable_cpus()
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(_v, str(N_CPU))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tests')):
@@ -61,14 +83,15 @@ def cpu_baseline(seconds_budget=20.0):
     t = time.time()
     O.render_rays(rays[320128:320384], sc, N_SAMPLES, N_IMPORTANCE, sf, white_bkgd=True)
     per_ray = (time.time() - t) / 256
-    n = int(max(256, min(8192, seconds_budget / per_ray)) // 256 * 256)
+    n = int(max(256, min(32768, seconds_budget / per_ray)) // 256 * 256)
     t = time.time()
     for s in range(0, n, 1024):
         O.render_rays(rays[320000 + s:320000 + min(n, s + 1024)], sc, N_SAMPLES, N_IMPORTANCE, sf, white_bkgd=True)
     dt = time.time() - t
-    return {'value': n / dt, 'unit': 'rays/s', 'cores': os.cpu_count(), 'kind': 'port',
+    return {'value': n / dt, 'unit': 'rays/s', 'cores': N_CPU, 'kind': 'port',
             'sample': '%d rays (pixels 320000..) of the same 800x800 view, 64+128 samples, D=8 W=256, numpy oracle '
-                      '(oracle/nerf.py, OpenBLAS sgemm on all host cores), %.1f s' % (n, dt)}
+                      '(oracle/nerf.py, OpenBLAS sgemm on the %d CPUs of the cgroup quota; the host reports %d), %.1f s'
+                      % (n, N_CPU, os.cpu_count() or 0, dt)}
 
 
 def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
@@ -120,11 +143,9 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     evals = n_rand * (N_SAMPLES + N_SAMPLES + N_IMPORTANCE)                           # coarse + fine network evaluations
     flop = evals * FLOP_PER_SAMPLE * 3                                                # fwd + bwd-data + bwd-weights
-    # On the shared GPU boxes single training steps (mostly of the exact-f32 section) sporadically take 30-110 ms instead
-    # of 8, most reliably in the first section of a process started right after another GPU process exited, sometimes
-    # as a 34 / 60 / 110 ms ramp at the end of a section. The kernels are the same ones as in the fast steps and bounding
-    # the host's run-ahead (above) does not remove it: it looks like clock / power management, not like this code. The
-    # section's rate is therefore the MEDIAN step; the whole-loop mean and every step's time are reported next to it.
+    # Before the CPU pools were sized to the cgroup quota (top of this file) single steps sporadically took 30-110 ms:
+    # CFS throttling of the launch thread. The section's rate is the MEDIAN step; the whole-loop mean and every step's
+    # time are reported next to it so that such an episode stays visible.
     mean_dt = dt
     dt = float(np.median(per_step)) * 1e-3
     out = {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand, 'precision': precision,

@@ -1,8 +1,28 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+
+def _usable_cpus():
+    """CPUs this process may use: cgroup quota (cpu.max) if set, else the affinity mask (same rule as bench.py)."""
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+# size the OpenMP / OpenBLAS pools to the cgroup quota before numpy / torch create them (the GPU boxes report 256 CPUs
+# and grant 16: oversubscribed pools get the whole process throttled)
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(_v, str(_usable_cpus()))
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'tests')):
