@@ -266,8 +266,13 @@ __device__ __forceinline__ void f16_part(f32x16 (&acc)[NT / SPC], WStream<NT>& w
 template <int NT, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
     constexpr int OTV = NT / 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4* ring = reinterpret_cast<u32x4*>(smem);
+    __shared__ __attribute__((aligned(16))) u32x4 ring_s[2 * WStream<NT>::CH];        // 2-slot weight ring
+    // The 12 encoding operands of a lane (pts: 4 k16-steps hi + lo, dirs: 2 + 2) are needed at layer 0, again at the
+    // skip layer and at the view layer. Parked in LDS in between they free 48 VGPRs inside the layer loop, where the
+    // compiler otherwise spilled ~30 registers per iteration to scratch - and every scratch reload queues behind the
+    // weight stream's global loads (vmcnt retires in order).
+    __shared__ __attribute__((aligned(16))) u32x4 s_enc[4][2 * kEmbK16 + 2 * kDirK16][64];
+    u32x4* ring = ring_s;
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int kViewsSteps = 2 * NT + kDirK16;                     // k16-steps of the views layer
     constexpr int kViewsChunks = (((kViewsSteps + 1) / 2) + 1) & ~1;  // 2 steps per chunk, padded to even
@@ -346,6 +351,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
             for (int q = 0; q < 8; ++q) v[q] = demb[8 * e + q];
             split8(v, dhi[e], dlo[e]);
         }
+#pragma unroll
+        for (int e = 0; e < kEmbK16; ++e) { s_enc[wave][e][lane] = ehi[e]; s_enc[wave][kEmbK16 + e][lane] = elo[e]; }
+#pragma unroll
+        for (int e = 0; e < kDirK16; ++e) { s_enc[wave][2 * kEmbK16 + e][lane] = dhi[e]; s_enc[wave][2 * kEmbK16 + kDirK16 + e][lane] = dlo[e]; }
 
         f32x16 acc[NT];
         u32x4 bh[NT][2], bl[NT][2];           // packed operands of the current layer input (hi / lo per k16-step)
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
             }
             load_bias_scaled<NT>(acc, P + L.b_off[l], h);
             if (l == L.skip + 1 && L.skip >= 0)
-                f16_part<NT, 1, kEmbK16, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = ehi[ks]; lo = elo[ks]; });
+                f16_part<NT, 1, kEmbK16, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = s_enc[wave][ks][lane]; lo = s_enc[wave][kEmbK16 + ks][lane]; });
             f16_part<NT, 1, 2 * NT, 0>(acc, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; });
             to_operands(l < L.D, 3 + l * NT);      // H_{l+1} for l < D, F for l == D
         }
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
         load_bias_scaled<OTV>(hv, P + L.b_off[L.D + 1], h);
         f16_part<NT, 2, kViewsChunks, kViewsPad>(hv, ws, ring, tid, lane, [&](int ks, u32x4& hi, u32x4& lo) {
             if (ks < 2 * NT) { hi = bh[ks >> 1][ks & 1]; lo = bl[ks >> 1][ks & 1]; }
-            else { hi = dhi[ks - 2 * NT]; lo = dlo[ks - 2 * NT]; }
+            else { hi = s_enc[wave][2 * kEmbK16 + ks - 2 * NT][lane]; lo = s_enc[wave][2 * kEmbK16 + kDirK16 + ks - 2 * NT][lane]; }
         });
         if (TRAIN && save) {
             TileMask<OTV> mk;
@@ -707,7 +716,7 @@ static int launch_f16(F16Args& a, int W, hipStream_t s) {
     long blocks = (ntiles + 3) / 4;
     if (blocks > cus) blocks = cus;
     const dim3 grid((unsigned)blocks), block(256);
-    const size_t lds = (size_t)2 * a.lay.NT * 2 * 64 * 16;          // 2-slot ring of NT*2 KB chunks
+    const size_t lds = 0;                                           // ring and parking lot are static LDS of the kernel
     const bool train = a.acts != nullptr;
     switch (W) {
         case 256: if (train) nerf_mlp_fwd_f16_kernel<8, true><<<grid, block, lds, s>>>(a); else nerf_mlp_fwd_f16_kernel<8, false><<<grid, block, lds, s>>>(a); break;
