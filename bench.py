@@ -127,9 +127,15 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(warmup):
+    # warm-up: at least `warmup` steps AND one second - for about a second after a process starts right behind another GPU
+    # process (a test run, say) every step of this short section took ~60 ms instead of 8; a single render view is
+    # longer than that window, this section is not
+    t_w = time.time()
+    n_w = 0
+    while n_w < warmup or time.time() - t_w < 1.0:
         step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        n_w += 1
     t = time.time()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     marks[0].record()

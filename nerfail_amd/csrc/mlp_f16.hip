@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
                         v[q] = relu ? fmaxf(x, 0.f) : x;
                         if (TRAIN && save) {
                             const int r = 8 * sgrp + q;
-                            lpA[(slot0 + t) * 1024 + acc_reg_off(r)] = v[q];
+                            slot_store(lpA + (slot0 + t) * 1024 + acc_reg_off(r), v[q]);
                             mk.w[t >> 1] |= relu_bit(v[q]) << (16 * (t & 1) + r);
                         }
                     }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_f16_kernel(F16Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float x = fmaxf(hv[t][r] * kWInv, 0.f);
-                    lpA[(3 + (L.D + 1) * NT + t) * 1024 + acc_reg_off(r)] = x;
+                    slot_store(lpA + (3 + (L.D + 1) * NT + t) * 1024 + acc_reg_off(r), x);
                     mk.w[t >> 1] |= relu_bit(x) << (16 * (t & 1) + r);
                 }
             store_mask<OTV>(A + train_mask_slot0(L.D, NT) * 1024, L.D, mk, lane);
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
                         const float g = wr[((0 * OTV + t) * 2 + h) * 16 + r] * dr.x + wr[((1 * OTV + t) * 2 + h) * 16 + r] * dr.y +
                                         wr[((2 * OTV + t) * 2 + h) * 16 + r] * dr.z;
                         const float dzv = mask_apply<OTV>(mhv, t, r, g);
-                        if (live) lpZ[(TL.z_ZV + t) * 1024 + acc_reg_off(r)] = dzv;
+                        if (live) slot_store(lpZ + (TL.z_ZV + t) * 1024 + acc_reg_off(r), dzv);
                         v[q] = dzv * S;
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_f16_kernel(F16BwdArg
                     for (int q = 0; q < 8; ++q) {
                         const int r = 8 * sgrp + q;
                         const float x = acc[t][r];
-                        if (live) lpZ[(slot0 + t) * 1024 + acc_reg_off(r)] = x * Sinv_old;
+                        if (live) slot_store(lpZ + (slot0 + t) * 1024 + acc_reg_off(r), x * Sinv_old);
                         v[q] = x * up;
                     }
                     split8(v, bh[t][sgrp], bl[t][sgrp]);

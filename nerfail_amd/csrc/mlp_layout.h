@@ -209,13 +209,23 @@ constexpr int kSlotCh = 16;                // floats between consecutive channel
 __device__ __forceinline__ int acc_lane_off(int lane) { return slot_pos(lane & 31) + (lane >> 5) * 4 * kSlotCh; }
 __device__ __forceinline__ constexpr int acc_reg_off(int r) { return ((r & 3) + 8 * (r >> 2)) * kSlotCh; }
 
+#ifndef NF_NT_STORE
+#define NF_NT_STORE 1
+#endif
+// One saved activation / gradient value: written once, read by a LATER kernel, 2 GB per pass. Stored non-temporal so
+// the stream does not push the 2.4 MB weight image (re-read by every workgroup for every tile) out of L2:
+// train-forward 16.1 -> 14.9 ms (f32) and 7.75 -> 7.15 ms (f16x3) at 1.57 M samples.
+__device__ __forceinline__ void slot_store(float* p, float v) {
+    if (NF_NT_STORE) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 template <int NTILES>
 __device__ __forceinline__ void store_tiles(float* __restrict__ base, const f32x16 (&a)[NTILES], int lane) {
     float* __restrict__ lp = base + acc_lane_off(lane);
 #pragma unroll
     for (int t = 0; t < NTILES; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lp[t * 1024 + acc_reg_off(r)] = a[t][r];
+        for (int r = 0; r < 16; ++r) slot_store(lp + t * 1024 + acc_reg_off(r), a[t][r]);
 }
 __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int lane) {
     const float* __restrict__ lp = base + acc_lane_off(lane);
