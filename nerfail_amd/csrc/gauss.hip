@@ -54,6 +54,18 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
     else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
+#ifndef NF_GAUSS_NT
+#define NF_GAUSS_NT 0
+#endif
+typedef float nf_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const nf_f4v v = __builtin_nontemporal_load(reinterpret_cast<const nf_f4v*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
+    const nf_f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nf_f4v*>(p));
+}
 __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict__ spatial, long Ns,
                                                         const float* __restrict__ wi, const float4* __restrict__ ori,
                                                         long B, long P, float epsilon, float4* __restrict__ x_out,
@@ -64,7 +76,9 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict
         const long b = g / P, p = g - b * P;
         const float4* w4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 0) * P + p) * 8);
         const float4* i4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 1) * P + p) * 8);
-        const float4 wa = w4[0], wb = w4[1], ia = i4[0], ib = i4[1];
+        // streamed once per pass: non-temporal, so the maps do not evict the perturbation rows the gathers want in cache
+        const float4 wa = NF_GAUSS_NT ? nt_load4(w4) : w4[0], wb = NF_GAUSS_NT ? nt_load4(w4 + 1) : w4[1];
+        const float4 ia = NF_GAUSS_NT ? nt_load4(i4) : i4[0], ib = NF_GAUSS_NT ? nt_load4(i4 + 1) : i4[1];
         const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
         const float fi[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
         float4 rows[8];
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict
             x.w = __fadd_rn(x.w, __fmul_rn(rows[k].w, w[k]));
         }
         const float alpha = __fdiv_rn(x.w, 255.0f);
-        const float4 o = ori[g];
+        const float4 o = NF_GAUSS_NT ? nt_load4(ori + g) : ori[g];
         float dlt[3] = {__fmul_rn(x.x, alpha), __fmul_rn(x.y, alpha), __fmul_rn(x.z, alpha)};
         if (alpha > 0.f) {                // GN:89-103 bookkeeping uses where(alpha>0, x, 0) * alpha
 #pragma unroll
@@ -98,8 +112,9 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict
             float v = (o.w > 0.f) ? __fadd_rn(oc[c], d) : 0.f;
             rgb[c] = fminf(fmaxf(v, 0.f), 255.f);
         }
-        x_out[g] = x;
-        x_rgba[g] = make_float4(rgb[0], rgb[1], rgb[2], fminf(fmaxf(o.w, 0.f), 255.f));
+        const float4 xr = make_float4(rgb[0], rgb[1], rgb[2], fminf(fmaxf(o.w, 0.f), 255.f));
+        if (NF_GAUSS_NT) { nt_store4(x_out + g, x); nt_store4(x_rgba + g, xr); }
+        else { x_out[g] = x; x_rgba[g] = xr; }
     }
     if (eps_minmax != nullptr) {
         emin = wave_min(emin);
