@@ -38,7 +38,7 @@ def _usable_cpus():
 # The GPU boxes report 256 CPUs but grant a 16-CPU cgroup quota. OpenMP / OpenBLAS pools sized for 256 then spin through
 # the quota and CFS throttles the whole process in 100 ms periods - seen as training steps of 30-110 ms instead of 8
 # (the launch thread simply did not run). Size the pools to what the process may use, BEFORE numpy / torch create them.
-N_CPU = _usable_cpus()
+N_CPU = max(1, _usable_cpus() // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))))     # per rank of this node
 for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
     os.environ.setdefault(_v, str(N_CPU))
 
