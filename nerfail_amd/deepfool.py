@@ -25,6 +25,11 @@ def deepfool(net_input, e, net, num_classes=8, max_iter=20, target_label: int = 
     if universal_2d:
         raise NotImplementedError('universal_2d is the 2-D baseline (attack_UAP_2D.py): out of scope, SURVEY.md section 2 #12')
     spatial_rgb, weight_and_index, ori_img = net_input
+    if torch.cuda.is_available():          # the reference keeps everything on `device` (AN:354-362); CPU tensors are uploaded once
+        dev = torch.device('cuda', torch.cuda.current_device())
+        spatial_rgb = _lib.f32c(torch.as_tensor(spatial_rgb), dev)
+        weight_and_index = _lib.f32c(torch.as_tensor(weight_and_index), dev)
+        ori_img = _lib.f32c(torch.as_tensor(ori_img), dev)
     spatial_rgb_0 = spatial_rgb.clone().detach()
     spatial_rgb = spatial_rgb.detach().clone().requires_grad_(True)
 

@@ -22,7 +22,10 @@ def test_deepfool_matches_reference(golden, tag, target, over, iters):
         def forward(self, x):
             return torch.nn.functional.adaptive_avg_pool2d(x, 4).reshape(x.shape[0], -1) @ w.t()
     net = gauss_net(dev(), 0.02, Cls(), 'my_model', epsilon=None)
-    rot, loop_i, ori_idx, cla_idx, s_new = deepfool((T(g['s']), T(g['wi']), T(g['ori'])), 1.0, net, num_classes=8,
+    # host tensors for the targeted case: deepfool uploads them once (the other cases pass device tensors)
+    inp = (torch.from_numpy(g['s']), torch.from_numpy(g['wi']), torch.from_numpy(g['ori'])) if tag == 'targeted' \
+        else (T(g['s']), T(g['wi']), T(g['ori']))
+    rot, loop_i, ori_idx, cla_idx, s_new = deepfool(inp, 1.0, net, num_classes=8,
                                                     max_iter=iters, target_label=target, overshoot=over, m1=0.05, m2=0.5)
     assert loop_i == int(g[tag + '_loop_i'])
     assert int(ori_idx) == int(g[tag + '_ori_idx']) and int(cla_idx) == int(g[tag + '_cla_idx'])
