@@ -44,19 +44,47 @@ def perturbation_grad(net, spatial, weight_and_index, ori_img, label, batch_tota
     return s.grad, loss.detach(), cla.detach()
 
 
-def nerfail_s_step(net, spatial, spatial_init, weight_and_index, ori_img, label, a=2.0, epsilon=32.0,
-                   targeted=False, group=None):
-    """One NeRFail-S iteration on one batch of views. Sharded over ranks when torch.distributed is up."""
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+def sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group=None, timing=None):
+    """d(mean CE over the WHOLE batch)/d(spatial), identical on every rank: this rank differentiates its contiguous
+    share of the batch's views (weight k/B), then ONE all-reduce sums the [P,H,W,4] gradient (C1).
+    `timing`: optional dict; gets HIP events around the collective ('allreduce_events') for bench.py."""
+    world, rank = sharding.world_and_rank(group)
     B = weight_and_index.shape[0]
     lo, hi = sharding.shard_range(B, rank, world)
     if hi > lo:
         g, loss, _ = perturbation_grad(net, spatial, weight_and_index[lo:hi], ori_img[lo:hi], label, batch_total=B)
-    else:
+    else:                                   # more ranks than views: this rank only takes part in the sum
         g = torch.zeros_like(spatial)
         loss = torch.zeros((), device=spatial.device)
     if world > 1:
+        if timing is not None and g.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         sharding.all_reduce_sum_(g, group)           # C1: the perturbation-gradient all-reduce
+        if timing is not None and g.is_cuda:
+            e1.record()
+            timing.setdefault('allreduce_events', []).append((e0, e1, g.numel() * g.element_size()))
         sharding.all_reduce_sum_(loss, group)
+    return g, loss
+
+
+def nerfail_s_step(net, spatial, spatial_init, weight_and_index, ori_img, label, a=2.0, epsilon=32.0,
+                   targeted=False, group=None, timing=None):
+    """One NeRFail-S iteration (AS:304-392) on one batch of views. Sharded over ranks when torch.distributed is up:
+    every rank ends with the identical perturbation tensor."""
+    g, loss = sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group, timing)
     return igsm_step(spatial, g, spatial_init, a, epsilon, targeted), loss
+
+
+def nerfail_s_loop(net, spatial, spatial_init, batches, label, iters, a=2.0, epsilon=32.0, targeted=False, group=None,
+                   on_iter=None):
+    """The AS:278-392 loop shape of BASELINE configs[2]: `iters` passes over `batches` (list of (weight_and_index,
+    ori_img) per batch of views), the perturbation updated after EVERY batch (sequential dependence, AS:306-392).
+    Returns the final perturbation; `on_iter(it, b, s, loss)` sees every iterate."""
+    s = spatial
+    for it in range(iters):
+        for b, (wi, ori) in enumerate(batches):
+            s, loss = nerfail_s_step(net, s, spatial_init, wi, ori, label, a, epsilon, targeted, group)
+            if on_iter is not None:
+                on_iter(it, b, s, loss)
+    return s

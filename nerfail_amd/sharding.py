@@ -3,8 +3,9 @@
 Rays are independent units: a view's pixel range is cut into contiguous per-rank ranges and rendered
 with NO data-path collective (each rank writes / keeps its own slice). The attack step has one real
 exchange: the sum of the per-shard perturbation gradients (attack.nerfail_s_step).
-Pure host logic: importable and testable without a GPU.
+The range arithmetic is pure host logic: importable and testable without a GPU.
 """
+import torch
 import torch.distributed as dist
 
 
@@ -21,10 +22,33 @@ def shard_ranges(n, world):
     return [shard_range(n, r, world) for r in range(world)]
 
 
+def world_and_rank(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+_STAGE = {}
+
+
 def all_reduce_sum_(t, group=None):
-    """In-place sum over ranks (RCCL all-reduce for HIP tensors, gloo for CPU tensors in the tests)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    """In-place sum over ranks. RCCL all-reduce for HIP tensors under the nccl backend (the GPU-box path, xGMI);
+    under any other backend (gloo: the CPU tests and the one-GPU rehearsal, where RCCL refuses two ranks on one
+    device) a HIP tensor is staged through a pinned host buffer, reduced there and copied back."""
+    world, _ = world_and_rank(group)
+    if world <= 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) != 'nccl':
+        key = (t.numel(), t.dtype)
+        h = _STAGE.get(key)
+        if h is None:
+            _STAGE.clear()
+            h = _STAGE[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+        h.copy_(t.reshape(-1), non_blocking=False)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h.reshape(t.shape))
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -33,3 +57,20 @@ def render_view_sharded(render_fn, H, W, rank, world):
     per-ray tensors; no collective is issued (the driver gathers or writes rank-local slices)."""
     lo, hi = shard_range(H * W, rank, world)
     return (lo, hi), render_fn(lo, hi - lo)
+
+
+def render_shard(H, W, K, c2w, near, far, rank=None, world=None, chunk=1024 * 32, group=None, **render_kwargs):
+    """This rank's contiguous pixel range of one view through the NC render pipeline (ray_gen of the range ->
+    batchify_rays incl. pts_max). Returns ((lo, hi), dict of per-ray tensors [hi-lo, ...]). Rays are independent, so
+    the per-rank slices concatenate BITWISE to the unsharded render (tests/test_hip_multigpu.py); no collective."""
+    from . import run_nerf as RN
+    if world is None:
+        world, rank = world_and_rank(group)
+    kw = {k: v for k, v in render_kwargs.items() if k not in ('ndc', 'use_viewdirs')}
+
+    def render_fn(lo, n):
+        if n == 0:
+            return {}
+        rays = RN.ray_gen(H, W, K, c2w, near, far, lo, n)
+        return RN.batchify_rays(rays, chunk, want_pts_max=True, **kw)
+    return render_view_sharded(render_fn, H, W, rank, world)

@@ -32,8 +32,46 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+_LAUNCHER = None
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # Multi-rank GPU tests need their rank processes started by a process that has NOT initialised the GPU (this one
+    # has, by the time the tests run): start the clean launcher now, before collection imports anything that does.
+    global _LAUNCHER
+    if os.path.exists('/dev/kfd') and _LAUNCHER is None:
+        import subprocess
+        _LAUNCHER = subprocess.Popen([sys.executable, '-u', os.path.join(ROOT, 'tests', 'mgpu', 'launcher.py')],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+
+
+def pytest_unconfigure(config):
+    global _LAUNCHER
+    if _LAUNCHER is not None:
+        try:
+            _LAUNCHER.stdin.close()
+            _LAUNCHER.wait(timeout=10)
+        except Exception:
+            _LAUNCHER.kill()
+        _LAUNCHER = None
+
+
+@pytest.fixture(scope='session')
+def rank_launcher():
+    """run(script, nproc, args=(), timeout=600) -> dict(rc=[...], logs=[...]) through tests/mgpu/launcher.py."""
+    import json
+    if _LAUNCHER is None:
+        pytest.skip('no /dev/kfd: the multi-rank GPU launcher was not started')
+
+    def run(script, nproc, args=(), timeout=600, env=None):
+        req = {'script': script, 'nproc': nproc, 'args': list(args), 'timeout': timeout, 'env': env or {}}
+        _LAUNCHER.stdin.write(json.dumps(req) + '\n')
+        _LAUNCHER.stdin.flush()
+        line = _LAUNCHER.stdout.readline()
+        assert line, 'launcher died'
+        return json.loads(line)
+    return run
 
 
 @pytest.fixture(scope='session')

@@ -1,0 +1,26 @@
+"""Deterministic inputs of the multi-rank product-path tests (numpy only: the rank scripts on the GPU and the
+oracle check on the CPU rebuild identical arrays from the seeds)."""
+import numpy as np
+
+import synth
+
+P, B, H, W = 3, 5, 24, 24            # 5 views over 2 ranks: ragged split 3 + 2
+LABEL, A, EPS, ITERS = 4, 2.0, 32.0, 3
+RH_, RW_ = 40, 40                    # sharded render: 1600 rays over 2 ranks
+
+
+def attack_inputs():
+    rs = np.random.RandomState(7)
+    s0 = np.zeros((P, H, W, 4), np.float32)
+    s0[..., 3] = np.where(rs.uniform(size=(P, H, W)) < 0.85, 255.0, 0.0)
+    ori = synth.disc_alpha_image(B, H, W, seed=8)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, (B, H, W, 8)).astype(np.float32)
+    cls_w = (rs.normal(size=(8, 3 * 4 * 4)) * 0.05).astype(np.float32)
+    return dict(s0=s0, ori=ori, dist_and_index=np.stack([dist, idx], 1), cls_w=cls_w)
+
+
+def render_inputs():
+    focal, K = synth.lego_intrinsics(RH_, RW_)
+    c2w = synth.pose_spherical(-60.0, -30.0, 4.0)[:3, :4]
+    return dict(K=K, c2w=c2w, seed_coarse=51, seed_fine=52)

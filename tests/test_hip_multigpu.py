@@ -1,0 +1,83 @@
+"""-m gpu: the multi-rank PRODUCT path, executed.
+
+Two fresh processes share the box's one GPU (gloo process group; nerfail_amd.sharding stages the HIP gradient through
+pinned host memory - RCCL refuses two ranks on one device). They run attack.nerfail_s_step on a ragged 5-view batch
+(3 + 2) and sharding.render_shard on one view; a 1-rank run of the SAME script is the comparison, the numpy oracle
+checks the gradient itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, rel_err
+from mgpu import problem as PB
+from oracle import gauss as OG
+
+pytestmark = pytest.mark.gpu
+SCRIPT = os.path.join(ROOT, 'tests', 'mgpu', 'rank.py')
+
+
+@pytest.fixture(scope='module')
+def runs(rank_launcher, tmp_path_factory):
+    out = tmp_path_factory.mktemp('mgpu')
+    for world in (1, 2):
+        rep = rank_launcher(SCRIPT, world, [str(out)], timeout=420)
+        assert rep['rc'] == [0] * world, '\n'.join(rep['logs'])
+    one = dict(np.load(out / 'w1_r0.npz'))
+    two = [dict(np.load(out / ('w2_r%d.npz' % r))) for r in range(2)]
+    return one, two
+
+
+def test_attack_step_two_ranks_identical_and_equal_to_one_rank(runs):
+    one, two = runs
+    for it in range(PB.ITERS):                      # every rank applies the identical step, every iteration
+        assert np.array_equal(two[0]['s_it%d' % it], two[1]['s_it%d' % it]), it
+    assert np.array_equal(two[0]['grad0'], two[1]['grad0'])
+    scale = np.abs(one['grad0']).max()
+    assert np.abs(two[0]['grad0'] - one['grad0']).max() <= 1e-5 * scale       # 2-rank sum == 1-rank gradient
+    assert abs(two[0]['loss0'] - one['loss0']) <= 1e-5 * abs(one['loss0'])
+    # sequential iterates: sign() may flip only where |grad| is at rounding level
+    for it in range(PB.ITERS):
+        diff = (two[0]['s_it%d' % it] != one['s_it%d' % it])
+        assert diff.mean() < 1e-3, (it, diff.mean())
+    s = one['s_it%d' % (PB.ITERS - 1)]
+    a = PB.attack_inputs()
+    assert np.array_equal(s[..., 3], a['s0'][..., 3])                          # alpha untouched
+    assert np.abs(s[..., :3] - a['s0'][..., :3]).max() <= PB.EPS
+    assert (s[..., :3][a['s0'][..., 3] == 0] == 0).all()
+
+
+def test_attack_gradient_matches_oracle(runs):
+    """The all-reduced gradient against the CPU restatement: oracle gauss forward -> torch CPU cold tail + CE (mean over
+    the whole batch) -> oracle gauss backward (AS:317-348 / GN:53-157)."""
+    one, two = runs
+    a = PB.attack_inputs()
+    wi, _ = OG.create_gauss_w(a['dist_and_index'])
+    assert rel_err(two[0]['wi'][:, 0], wi[:, 0]) < 1e-5
+    x, x_rgba, _ = OG.gauss_forward(a['s0'], wi, a['ori'], None)
+    xr = torch.from_numpy(x_rgba).requires_grad_(True)
+    c = xr.permute(0, 3, 1, 2)
+    img = torch.where(c[:, 3:4] > 0, c[:, :3], torch.full_like(c[:, :3], 255.))
+    cla = torch.nn.functional.adaptive_avg_pool2d(img, 4).reshape(PB.B, -1) @ torch.from_numpy(a['cls_w']).t()
+    loss = torch.nn.functional.cross_entropy(cla, torch.full((PB.B,), PB.LABEL, dtype=torch.long))
+    loss.backward()
+    ref = OG.gauss_backward(a['s0'], wi, a['ori'], np.zeros_like(x), xr.grad.numpy(), None)
+    assert abs(two[0]['loss0'] - float(loss)) <= 1e-5 * abs(float(loss))
+    assert rel_err(two[0]['grad0'], ref) < 1e-4
+    assert rel_err(one['grad0'], ref) < 1e-4
+    assert np.array_equal(two[0]['s_it0'], OG.igsm_step(a['s0'], two[0]['grad0'], a['s0'], PB.A, PB.EPS, False))
+
+
+def test_render_shards_concatenate_bitwise(runs):
+    one, two = runs
+    n = PB.RH_ * PB.RW_
+    assert (int(two[0]['render_lo']), int(two[0]['render_hi'])) == (0, n // 2)
+    assert (int(two[1]['render_lo']), int(two[1]['render_hi'])) == (n // 2, n)
+    for k in ('rgb_map', 'disp_map', 'acc_map', 'pts_max'):
+        cat = np.concatenate([two[0]['render_' + k], two[1]['render_' + k]], 0)
+        full = one['full_' + k]
+        assert cat.shape == full.shape, k
+        assert np.array_equal(cat.view(np.uint32), full.view(np.uint32)), k     # bitwise, NaNs of disp included
+        assert np.array_equal(one['render_' + k].view(np.uint32), full.view(np.uint32)), k
+    assert np.isfinite(one['full_rgb_map']).all() and (one['full_acc_map'] > 0).any()

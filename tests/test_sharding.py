@@ -1,6 +1,6 @@
-"""Host logic of the multi-GPU decomposition, incl. a world_size-2 gloo run of the attack step's one
-collective (perturbation-gradient all-reduce). Compute inside the ranks is the ORACLE (the product has no CPU
-path); what is under test is nerfail_amd.sharding / the reduce-then-step structure of attack.nerfail_s_step."""
+"""Host logic of the multi-GPU decomposition, incl. a world_size-2 gloo run of the PRODUCT's
+attack.sharded_perturbation_grad (shard range, k/B weighting, the one all-reduce) with a torch-CPU stand-in for
+gauss_net (the HIP kernels have no CPU path; tests/test_hip_multigpu.py runs the same thing on the GPU with them)."""
 import os
 import socket
 import sys
@@ -34,34 +34,43 @@ def _free_port():
     return p
 
 
+def _torch_gauss_net(cls_w):
+    """Differentiable torch-CPU stand-in with gauss_net's call contract (GN:46-159), so that the PRODUCT's
+    attack.sharded_perturbation_grad (shard range, k/B weighting, the C1 all-reduce) runs unchanged on CPU ranks."""
+    def net(s, wi, ori):
+        w, idx = wi[:, 0], wi[:, 1].long()
+        x = (s.reshape(-1, 4)[idx] * w[..., None]).sum(3)
+        rgb = torch.where(ori[..., 3:4] > 0, ori[..., :3] + x[..., :3] * (x[..., 3:4] / 255.), torch.zeros(()))
+        x_rgba = torch.clip(torch.cat([rgb, ori[..., 3:4]], -1), 0., 255.)
+        c = x_rgba.permute(0, 3, 1, 2)
+        img = torch.where(c[:, 3:4] > 0, c[:, :3], torch.full_like(c[:, :3], 255.))
+        cla = torch.nn.functional.adaptive_avg_pool2d(img, 4).reshape(c.shape[0], -1) @ cls_w.t()
+        return x, x_rgba, cla, ori, None
+    return net
+
+
 def _worker(rank, world, port, out_dir):
     sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]
     from oracle import gauss as OG
-    import synth
+    from mgpu import problem as PB
+    from nerfail_amd import attack
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    rs = np.random.RandomState(0)
-    P, B, H, W = 3, 5, 12, 12                                   # 5 views over 2 ranks: ragged split 3 + 2
-    s = rs.uniform(-20, 20, (P, H, W, 4)).astype(np.float32)
-    s[..., 3] = 255.0
-    ori = synth.disc_alpha_image(B, H, W, seed=1)
-    dist_ = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
-    idx = rs.randint(0, P * H * W, (B, H, W, 8)).astype(np.float32)
-    wi, _ = OG.create_gauss_w(np.stack([dist_, idx], 1))
-    G = rs.normal(size=(B, H, W, 4)).astype(np.float32) / B     # stands in for d(mean CE)/d(x_rgba)
-    lo, hi = sharding.shard_range(B, rank, world)
-    g = OG.gauss_backward(s, wi[lo:hi], ori[lo:hi], np.zeros_like(G[lo:hi]), G[lo:hi], None)
-    gt = torch.from_numpy(g)
-    sharding.all_reduce_sum_(gt)                                # C1
-    out = OG.igsm_step(s, gt.numpy(), s, 2.0, 32.0, False)
+    a = PB.attack_inputs()                                      # 5 views over 2 ranks: ragged split 3 + 2
+    wi, _ = OG.create_gauss_w(a['dist_and_index'])
+    net = _torch_gauss_net(torch.from_numpy(a['cls_w']))
+    s0, ori = torch.from_numpy(a['s0']), torch.from_numpy(a['ori'])
+    g, loss = attack.sharded_perturbation_grad(net, s0, torch.from_numpy(wi), ori, torch.tensor(PB.LABEL))   # product code + C1
+    out = OG.igsm_step(a['s0'], g.numpy(), a['s0'], PB.A, PB.EPS, False)
     np.save(os.path.join(out_dir, 'rank%d.npy' % rank), out)
-    if rank == 0:
-        full = OG.gauss_backward(s, wi, ori, np.zeros_like(G), G, None)
-        np.save(os.path.join(out_dir, 'full_grad.npy'), full)
-        np.save(os.path.join(out_dir, 'sum_grad.npy'), gt.numpy())
-        np.save(os.path.join(out_dir, 'single.npy'), OG.igsm_step(s, full, s, 2.0, 32.0, False))
+    np.save(os.path.join(out_dir, 'grad%d.npy' % rank), g.numpy())
     dist.destroy_process_group()
+    if rank == 0:                                               # the same product function, no process group: 1 rank
+        full, loss1 = attack.sharded_perturbation_grad(net, s0, torch.from_numpy(wi), ori, torch.tensor(PB.LABEL))
+        assert abs(float(loss) - float(loss1)) <= 1e-6 * abs(float(loss1))
+        np.save(os.path.join(out_dir, 'full_grad.npy'), full.numpy())
+        np.save(os.path.join(out_dir, 'single.npy'), OG.igsm_step(a['s0'], full.numpy(), a['s0'], PB.A, PB.EPS, False))
 
 
 def test_attack_step_all_reduce_gloo_world2(tmp_path):
@@ -69,10 +78,19 @@ def test_attack_step_all_reduce_gloo_world2(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
     assert np.array_equal(r0, r1)                               # every rank applies the identical step
-    full, summed = np.load(tmp_path / 'full_grad.npy'), np.load(tmp_path / 'sum_grad.npy')
+    assert np.array_equal(np.load(tmp_path / 'grad0.npy'), np.load(tmp_path / 'grad1.npy'))
+    full, summed = np.load(tmp_path / 'full_grad.npy'), np.load(tmp_path / 'grad0.npy')
+    assert np.abs(full).max() > 0
     assert np.abs(full - summed).max() <= 1e-5 * np.abs(full).max()   # N-rank sum == 1-rank gradient (fp32 order)
     single = np.load(tmp_path / 'single.npy')
     assert (r0 != single).mean() < 1e-3                         # sign() can flip only where |grad| ~ rounding
+
+
+def test_all_reduce_stages_through_host_only_off_nccl():
+    """Without a process group the reduce is the identity (and does not touch the tensor)."""
+    t = torch.arange(6.)
+    assert sharding.all_reduce_sum_(t) is t and torch.equal(t, torch.arange(6.))
+    assert sharding.world_and_rank() == (1, 0)
 
 
 def test_render_shards_need_no_collective():
