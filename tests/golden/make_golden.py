@@ -570,8 +570,134 @@ def g14():
     save('g14_render_options', **out)
 
 
+# ---------------------------------------------------------------- G15 cfg3: the 20-iteration NeRFail-S loop, 2 batches x 8 views
+def g15():
+    """BASELINE configs[2] at fixture size: the AS:278-392 loop (reference gauss_net forward, CrossEntropyLoss, backward,
+    the re-issued sign step AS:352-392) for 20 iterations over 16 views in 2 batches of 8, perturbation updated after
+    EVERY batch. Stores the perturbation after each of the 40 steps (int8 offsets from the zero init: every value is a
+    multiple of a = 2 within +-32) and the loss of every step."""
+    rs = np.random.RandomState(15)
+    P, H, W, NB, B, ITERS = 3, 16, 16, 2, 8, 20
+    s0 = np.zeros((P, H, W, 4), np.float32)
+    s0[..., 3] = np.where(rs.uniform(size=(P, H, W)) < 0.85, 255.0, 0.0)
+    ori = synth.disc_alpha_image(NB * B, H, W, seed=16)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(NB * B, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, size=(NB * B, H, W, 8)).astype(np.float32)
+    with torch.no_grad():
+        wi, _ = GN.create_gauss_w('cpu', 0.02)(T(np.stack([dist, idx], 1)))
+    cls = _PoolCls()
+    with torch.no_grad():
+        cls.w.mul_(4.0)
+    for p_ in cls.parameters():
+        p_.requires_grad = False
+    net = GN.gauss_net('cpu', 0.02, cls, 'my_model', epsilon=None)
+    criterion = torch.nn.CrossEntropyLoss()
+    label = torch.tensor(4)
+    a, epsilon = 2.0, 32.0
+    s_init = T(s0)
+    s = T(s0).clone()
+    iterates, losses, min_abs_grad = [], [], []
+    for it in range(ITERS):
+        for b in range(NB):
+            st = s.clone().detach().requires_grad_(True)                       # AS:306
+            x, r, cla, ori_f, ori_cla = net(st, wi[b * B:(b + 1) * B], T(ori[b * B:(b + 1) * B]), True)   # AS:317
+            lab = label.broadcast_to([ori_cla.size()[0], ])
+            total_loss = 1.0 * criterion(cla, lab) + 0.0 * torch.nn.functional.mse_loss(r, ori_f)   # AS:328-336, beta = 0
+            total_loss.backward()
+            g = st.grad
+            nz = g[..., :3][(g[..., :3] != 0)]
+            min_abs_grad.append(float(nz.abs().min()) if nz.numel() else 0.0)
+            with torch.no_grad():
+                s = ref_igsm_step(st.detach(), g, s_init, a, epsilon, False)
+            iterates.append(s[..., :3].numpy().astype(np.int8))
+            assert np.array_equal(iterates[-1].astype(np.float32), s[..., :3].numpy())
+            losses.append(float(total_loss))
+    print('g15 loss %.4f -> %.4f, smallest nonzero |grad| over the run %.3e' % (losses[0], losses[-1], min(min_abs_grad)))
+    save('g15_cfg3_loop', s0=s0, ori=ori, wi=wi.numpy(), cls_w=cls.w.detach().numpy(), label=4, a=a, epsilon=epsilon,
+         iterates_rgb_int8=np.stack(iterates), losses=np.array(losses, np.float64),
+         min_abs_grad=np.array(min_abs_grad, np.float64), shape=np.array([P, H, W, NB, B, ITERS]))
+
+
+# ---------------------------------------------------------------- G16 NeRF.forward + autograd on identical inputs (a12 isolated)
+def g16():
+    """Parameter gradients of sum(raw * d_raw) through the reference's Embedder + NeRF.forward (RH:15-50, :100-123) under
+    torch autograd (RN:791), D=8 W=256, 16 rays x 128 samples, upstream gradient spanning 6 decades. Also the SAME graph
+    in float64: the per-parameter L2 distance fp32-vs-fp64 is the reference's own rounding noise (incl. its ReLU-mask
+    flips) and sets the test bound for the HIP backward (2x that, not a flat tolerance)."""
+    rs = np.random.RandomState(16)
+    R, N = 16, 128
+    rays = synth.ray_batch(R, seed=160)
+    z = np.sort(rs.uniform(2, 6, size=(R, N)).astype(np.float32), -1)
+    pts = (rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None]).astype(np.float32)
+    dirs = rays[:, 8:11].copy()
+    d_raw = (rs.normal(size=(R, N, 4)) * 10.0 ** rs.uniform(-4, 2, size=(R, N, 1))).astype(np.float32)
+    sd = synth.nerf_state_dict(seed=161)
+    out = dict(pts=pts, dirs=dirs, d_raw=d_raw, seed=161)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        net = RH.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        net.load_state_dict({k: T(v) for k, v in sd.items()})
+        net = net.to(dt)
+        e10, _ = RH.get_embedder(10, 0)
+        e4, _ = RH.get_embedder(4, 0)
+        raw = RN.run_network(T(pts).to(dt), T(dirs).to(dt), net, e10, e4, netchunk=1024 * 64)
+        (raw * T(d_raw).to(dt)).sum().backward()
+        grads[dt] = {k: p.grad.detach().numpy() for k, p in net.named_parameters()}
+        if dt == torch.float32:
+            out['raw'] = raw.detach().numpy()
+    worst = 0.0
+    for k, g32 in grads[torch.float32].items():
+        g64 = grads[torch.float64][k]
+        e = float(np.linalg.norm(g32.astype(np.float64) - g64) / max(np.linalg.norm(g64), 1e-300))
+        out['grad_' + k] = g32
+        out['ref_err_' + k] = e
+        worst = max(worst, e)
+        print('  g16 %-28s |g| %.3e  reference fp32-vs-fp64 L2 err %.2e' % (k, np.linalg.norm(g64), e))
+    print('g16 worst reference fp32-vs-fp64 gradient L2 error: %.2e' % worst)
+    save('g16_mlp_backward', **out)
+
+
+# ---------------------------------------------------------------- G17 8-NN -> weights -> x: the reference PIPELINE vs exact 8-NN
+def g17():
+    """The reference's own chain CI:126-145 (re-issued, torch.cdist matmul path) -> create_gauss_w (GN:169-186) ->
+    gauss_net.forward x (GN:53-83) on a point cloud with the REAL regime's geometry: neighbour spacing ~0.003 << c = 0.02
+    (1.92 M points on a unit-scale object), coordinates O(1), and exact hits (a base view's own pixels are in the set).
+    The HIP chain K8 -> K9 -> K10 uses the exact 8-NN definition; the test measures how far x moves."""
+    rs = np.random.RandomState(17)
+    P, H, W = 3, 32, 32
+    n = P * H * W
+
+    def patch(m, seed):
+        r = np.random.RandomState(seed)
+        c = np.array([0.6, 0.5, 0.62]) / np.linalg.norm([0.6, 0.5, 0.62])
+        t1 = np.cross(c, [0, 0, 1.0]); t1 /= np.linalg.norm(t1)
+        t2 = np.cross(c, t1)
+        uv = r.uniform(-0.085, 0.085, size=(m, 2))
+        p = c[None] + uv[:, :1] * t1[None] + uv[:, 1:] * t2[None]
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+        return (p * (1.0 + 0.002 * (2 * r.uniform(size=(m, 1)) - 1))).astype(np.float32)
+    S = patch(n, 170)
+    Q = patch(H * W, 171).reshape(H, W, 3)
+    Q[0, :16] = S[:16]                     # exact hits: the pixel's own 3-D point is in the set
+    Q[1, :16] = S[2000:2016]
+    dai = ref_knn_procedure(T(Q), T(S), split_parts=4)            # [2,H,W,8] float32
+    with torch.no_grad():
+        wi, _ = GN.create_gauss_w('cpu', 0.02)(dai.unsqueeze(0))
+    s = rs.uniform(-32, 32, size=(P, H, W, 4)).astype(np.float32)
+    s[..., 3] = 255.0
+    ori = synth.disc_alpha_image(1, H, W, seed=172)
+    net = GN.gauss_net('cpu', 0.02, _PoolCls(), 'my_model', epsilon=None)
+    with torch.no_grad():
+        x, x_rgba, _, _, _ = net(T(s), wi, T(ori))
+    d64 = np.linalg.norm(Q.reshape(-1, 1, 3).astype(np.float64) - S[None].astype(np.float64), axis=-1)
+    order = np.argsort(d64, axis=-1, kind='stable')[:, :8]
+    save('g17_knn_pipeline', S=S, Q=Q, ref_dist_and_index=dai.numpy(), ref_wi=wi.numpy(), s=s, ori=ori,
+         ref_x=x.numpy(), ref_x_rgba=x_rgba.numpy(), exact64_idx=order.astype(np.int32),
+         exact64_dist=np.take_along_axis(d64, order, -1))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
     for w in which:
         globals()[w]()
 

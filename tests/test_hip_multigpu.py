@@ -63,7 +63,7 @@ def test_attack_gradient_matches_oracle(runs):
     loss = torch.nn.functional.cross_entropy(cla, torch.full((PB.B,), PB.LABEL, dtype=torch.long))
     loss.backward()
     ref = OG.gauss_backward(a['s0'], wi, a['ori'], np.zeros_like(x), xr.grad.numpy(), None)
-    assert abs(two[0]['loss0'] - float(loss)) <= 1e-5 * abs(float(loss))
+    assert abs(two[0]['loss0'] - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
     assert rel_err(two[0]['grad0'], ref) < 1e-4
     assert rel_err(one['grad0'], ref) < 1e-4
     assert np.array_equal(two[0]['s_it0'], OG.igsm_step(a['s0'], two[0]['grad0'], a['s0'], PB.A, PB.EPS, False))

@@ -36,3 +36,44 @@ def test_igsm_step_matches_reference(golden):
     for targeted in (False, True):
         out = O.igsm_step(g['s'], g['grad'], g['s_init'], 2.0, 32.0, targeted)
         assert np.array_equal(out, g['out_targeted%d' % int(targeted)])
+
+
+def oracle_cfg3_loop(g):
+    """The cfg3 loop (AS:278-392) with the numpy oracle for the pixel<->3-D map and torch-CPU for the stand-in
+    classifier tail (GN:121-157) + CE; yields the perturbation rgb after every step. Shared with the GPU test."""
+    import torch
+    P, H, W, NB, B, ITERS = [int(v) for v in g['shape']]
+    s0, ori, wi = g['s0'], g['ori'], g['wi']
+    cls_w = torch.from_numpy(g['cls_w'])
+    s = s0.copy()
+    for it in range(ITERS):
+        for b in range(NB):
+            sl = slice(b * B, (b + 1) * B)
+            x, x_rgba, _ = O.gauss_forward(s, wi[sl], ori[sl], None)
+            xr = torch.from_numpy(x_rgba).requires_grad_(True)
+            c = xr.permute(0, 3, 1, 2)
+            img = torch.where(c[:, 3:4] > 0, c[:, :3], torch.full_like(c[:, :3], 255.))
+            cla = torch.nn.functional.adaptive_avg_pool2d(img, 4).reshape(B, -1) @ cls_w.t()
+            loss = torch.nn.functional.cross_entropy(cla, torch.full((B,), int(g['label']), dtype=torch.long))
+            loss.backward()
+            grad = O.gauss_backward(s, wi[sl], ori[sl], np.zeros_like(x), xr.grad.numpy(), None)
+            s = O.igsm_step(s, grad, s0, float(g['a']), float(g['epsilon']), False)
+            yield it, b, s, float(loss.detach())
+
+
+def test_cfg3_loop_matches_reference_iterates(golden):
+    """Fixture g15: 20 iterations x 2 batches of 8 views through the reference's gauss_net + the re-issued sign step.
+    The update is a sign step: an element may differ from the reference only where its gradient is at rounding level,
+    and such a flip moves later iterates by one step of a = 2 at that element."""
+    g = golden('g15_cfg3_loop')
+    ref = g['iterates_rgb_int8'].astype(np.float32)
+    worst, step = 0.0, 0
+    for it, b, s, loss in oracle_cfg3_loop(g):
+        diff = s[..., :3] != ref[step]
+        worst = max(worst, float(diff.mean()))
+        assert np.abs(s[..., :3] - ref[step]).max() <= 2 * float(g['a']), (it, b)
+        assert abs(loss - g['losses'][step]) <= 2e-4 * abs(g['losses'][step]), (it, b, loss, g['losses'][step])
+        step += 1
+    assert step == 40
+    print('oracle vs reference cfg3 iterates: worst fraction of differing elements %.2e' % worst)
+    assert worst < 2e-3

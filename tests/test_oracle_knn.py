@@ -67,3 +67,67 @@ def test_knn_against_reference_procedure_where_separated(golden):
         assert well.mean() > 0.5
         assert (i[well] == ri[well]).all()
         assert (np.abs(d - rd)[well] <= bound[well]).all()
+
+
+def agreement_with_reference(d, i, rd, ri):
+    """How an exact 8-NN result (d, i) relates to the reference procedure's output (rd, ri), per query row of 8."""
+    same_set = np.array([set(a) == set(b) for a, b in zip(i, ri)])
+    rel = np.abs(d - rd) / np.maximum(rd, 1e-12)
+    return dict(ordered=float((i == ri).mean()), rows=float((i == ri).all(-1).mean()), sets=float(same_set.mean()),
+                max_rel_dist=float(rel[rd > 1e-3].max()) if (rd > 1e-3).any() else 0.0,
+                max_abs_dist_at_exact_hits=float(np.abs(rd - d)[d == 0].max()) if (d == 0).any() else 0.0)
+
+
+def test_measured_agreement_with_reference_procedure(golden):
+    """The numbers behind 'bit-exact against the exact definition, not against torch.cdist' (BASELINE.md section 5), asserted:
+    the reference's matmul-path cdist (|a|^2 + |b|^2 - 2ab) mis-orders a fraction of a percent of its own entries and
+    reports nonzero self-distances; the index SETS agree except where the 8th/9th gap is below its noise."""
+    g = golden('g8_knn')
+    for tag, lim in (('a', dict(ordered=0.985, sets=0.995)), ('b', dict(ordered=0.995, sets=0.999))):
+        Q, S = _case(g, tag)
+        out = O.index_and_dist(Q, S)
+        ref = g[tag + '_ref']
+        m = agreement_with_reference(out[0].reshape(-1, 8), out[1].reshape(-1, 8).astype(np.int64),
+                                     ref[0].reshape(-1, 8), ref[1].reshape(-1, 8).astype(np.int64))
+        print('8-NN oracle vs reference procedure, case %s: ordered indices %.4f, full rows %.4f, index sets %.4f, '
+              'max rel distance deviation %.3e, reference self-distance at exact hits up to %.3e'
+              % (tag, m['ordered'], m['rows'], m['sets'], m['max_rel_dist'], m['max_abs_dist_at_exact_hits']))
+        assert m['ordered'] >= lim['ordered'] and m['sets'] >= lim['sets'], m
+        assert m['max_rel_dist'] < 0.08, m
+        assert m['max_abs_dist_at_exact_hits'] < 1e-3, m
+
+
+def pipeline_deviation(x, ref_x):
+    """Fraction of pixels whose gathered perturbation x moves by more than 1e-4 of the tensor maximum, and the max."""
+    scale = np.abs(ref_x).max()
+    dev = np.abs(x - ref_x).max(-1) / scale
+    return float((dev > 1e-4).mean()), float(dev.max())
+
+
+def test_pipeline_deviation_from_reference_chain(golden):
+    """Fixture g17: reference chain CI:126-145 -> create_gauss_w -> gauss_net x, in the real regime (spacing << c,
+    exact hits present), vs the exact-8-NN chain of the oracle. The 8-NN sets agree; what moves x is the reference's
+    noisy DISTANCES (weights exp(-(d/c)^2/2)): measured and bounded here, recorded in DESIGN.md section 2."""
+    from oracle import gauss as OG
+    g = golden('g17_knn_pipeline')
+    out = O.index_and_dist(g['Q'], g['S'])
+    ref = g['ref_dist_and_index']
+    m = agreement_with_reference(out[0].reshape(-1, 8), out[1].reshape(-1, 8).astype(np.int64),
+                                 ref[0].reshape(-1, 8), ref[1].reshape(-1, 8).astype(np.int64))
+    ex = g['exact64_idx']
+    assert (np.sort(out[1].reshape(-1, 8).astype(np.int64), -1) == np.sort(ex, -1)).all(-1).mean() > 0.995
+    assert np.abs(out[0].reshape(-1, 8) - g['exact64_dist']).max() < 1e-6
+    wi, _ = OG.create_gauss_w(out[None])
+    x, x_rgba, _ = OG.gauss_forward(g['s'], wi, g['ori'], None)
+    frac, worst = pipeline_deviation(x, g['ref_x'])
+    # the same chain fed with the REFERENCE's own (dist, idx) reproduces its x: the deviation is all in the 8-NN stage
+    wi_r, _ = OG.create_gauss_w(ref[None])
+    x_r, _, _ = OG.gauss_forward(g['s'], wi_r, g['ori'], None)
+    frac_r, worst_r = pipeline_deviation(x_r, g['ref_x'])
+    print('g17 (spacing << c, exact hits): ordered %.4f rows %.4f sets %.4f; max rel distance dev %.3e; self-distance '
+          'up to %.3e; pixels with |dx| > 1e-4 max|x|: %.4f (worst %.3e); same chain on the reference\'s own 8-NN output: '
+          '%.4f (worst %.3e)' % (m['ordered'], m['rows'], m['sets'], m['max_rel_dist'], m['max_abs_dist_at_exact_hits'],
+                                 frac, worst, frac_r, worst_r))
+    assert frac_r == 0.0 and worst_r < 1e-5
+    assert m['sets'] > 0.97
+    assert worst < 0.05 and frac < 0.9

@@ -162,3 +162,20 @@ def test_render_options_match_reference(golden):
                       noise=(draw(R, 64) * 0.5).astype(np.float32), noise_fine=(draw(R, 192) * 0.5).astype(np.float32))
     for k in keys:
         assert rel_err(r[k], g['b_' + k]) < 1e-4, k
+
+
+def test_mlp_backward_on_identical_inputs(golden):
+    """Fixture g16: the reference's Embedder + NeRF.forward + autograd on fixed points, upstream gradient over 6
+    decades. Bound per parameter = 2 x the reference's own fp32-vs-fp64 L2 error (stored in the fixture) + the oracle's
+    different embedding rounding (numpy vs torch sin/cos, ~1e-7 abs): a flat 2e-6 floor."""
+    g = golden('g16_mlp_backward')
+    sd = synth.nerf_state_dict(seed=int(g['seed']))
+    raw, cache = O._mlp_forward_cached(sd, g['pts'], g['dirs'], 8, 256)
+    assert rel_err(raw, g['raw']) < 1e-4
+    grads = O.mlp_backward(sd, cache, g['d_raw'], 8, 256)
+    worst = 0.0
+    for k, v in grads.items():
+        e = l2_err(v, g['grad_' + k])
+        worst = max(worst, e / (2 * float(g['ref_err_' + k]) + 2e-6))
+        assert e <= 2 * float(g['ref_err_' + k]) + 2e-6, (k, e, float(g['ref_err_' + k]))
+    print('oracle mlp_backward vs reference autograd: worst error / bound = %.2f' % worst)
