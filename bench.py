@@ -63,6 +63,40 @@ PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f
 HBM_PEAK_GBS = 8000.0
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over nerfail_amd/csrc: ties a stored PMC measurement to the kernels it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'nerfail_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
+
+
+def pmc_traffic(kernel_substr):
+    """HBM(+Infinity Cache) bytes per launch of a kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 +
+    WRITE_SIZE, MI355X_MICROARCH.md; tools/pmc_traffic.py writes the file). PMC counters cannot be read from inside this
+    process, so the number is a stored measurement: it is reported ONLY if the file was taken from the very kernel
+    sources this run uses (csrc hash) - otherwise null, with the reason."""
+    try:
+        pmc = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None, 'no PMC file (%s)' % os.path.basename(PMC_FILE)
+    if pmc.get('csrc_sha16') != kernel_source_hash():
+        return None, 'stale: %s was measured on csrc %s, this run is %s' % (os.path.basename(PMC_FILE), pmc.get('csrc_sha16'),
+                                                                          kernel_source_hash())
+    for name, v in pmc.get('kernels', {}).items():
+        if kernel_substr in name:
+            return (v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch'],
+                    {'file': 'profiles/' + os.path.basename(PMC_FILE), 'command': pmc.get('command'), 'csrc_sha16': pmc.get('csrc_sha16')})
+    return None, 'kernel not in ' + os.path.basename(PMC_FILE)
+
+
 def make_net(seed, dev):
     from nerfail_amd.run_nerf_helpers import NeRF
     sd = synth.nerf_state_dict(D=NET_D, W=NET_W, seed=seed)
@@ -157,6 +191,9 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     out = {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand, 'precision': precision,
            'final_loss': float(loss.detach()), 'fp32_equivalent_tflops_whole_step': flop / dt / 1e12,
            'statistic': 'median of the %d timed steps' % steps, 'ms_per_step_mean_whole_loop': mean_dt * 1e3,
+           'note': 'kernel metric: the step omits the reference loop\'s per-iteration HOST work - get_rays on the full image '
+                   '(RN:752) and np.random.choice(H*W, N_rand) (RN:768, a 6-15 ms host permutation); rays are gathered from a '
+                   'precomputed all_rays with torch.randperm on the device',
            'ms_per_step_each': [round(v, 3) for v in per_step]}
     if precision == 'f32':      # the three GEMM families run on the exact-f32 MFMA: that pipe bounds the step
         out['roofline'] = {'bound': 'mfma', 'achieved': flop / dt / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -251,15 +288,7 @@ def attack_bench(dev, iters=5):
     from nerfail_amd.attack import igsm_step, nerfail_s_step
     rs = np.random.RandomState(0)
     P, B = 3, 8
-    Ns = P * H * W
-    # neighbours drawn near the pixel's own index in one base view: locality like a real 8-NN map
-    base = (rs.randint(0, P, size=(B, 1, 1, 1)) * H * W + np.arange(H * W).reshape(1, H, W, 1))
-    idx = np.clip(base + rs.randint(-2 * W, 2 * W, size=(B, H, W, 8)), 0, Ns - 1).astype(np.float32)
-    dist_ = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
-    wi, _ = create_gauss_w(dev, 0.02)(torch.from_numpy(np.stack([dist_, idx], 1)).to(dev))
-    ori = torch.from_numpy(synth.disc_alpha_image(B, H, W, seed=3)).to(dev)
-    s_init = torch.zeros((P, H, W, 4), device=dev)
-    s_init[..., 3] = 255.0
+    wi, ori, s_init = _attack_inputs(dev, B, seed=0)          # maps built by K8 + K9 on the synthetic shell point set
     G = torch.from_numpy(rs.normal(size=(B, H, W, 4)).astype(np.float32)).to(dev)
     out = {}
 
@@ -293,6 +322,20 @@ def attack_bench(dev, iters=5):
     dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
     out['end_to_end_victim_cnn'] = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
                                     'note': 'gauss_net.forward (2 classifier forwards) + CE + backward + sign step'}
+    # the same with MIOpen allowed to search for its solvers (torch.backends.cudnn.benchmark) and a channels-last victim:
+    # in the default configuration MIOpen falls back to naive_conv_* kernels for some of these 800x800 layers
+    if os.environ.get('NERFAIL_BENCH_TUNE_VICTIM', '1') == '1':
+        t_tune = time.time()
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = True
+        victim_t = victim_cnn(8).to(dev).to(memory_format=torch.channels_last).requires_grad_(False)
+        victim_t.load_state_dict(victim.state_dict())
+        net_t = gauss_net(dev, 0.02, victim_t, 'my_model', epsilon=None)
+        dt = timed(lambda s: nerfail_s_step(net_t, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
+        torch.backends.cudnn.benchmark = prev
+        out['end_to_end_victim_cnn_tuned_miopen'] = {
+            'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3, 'solver_search_seconds': time.time() - t_tune - dt * (iters + 1),
+            'note': 'torch.backends.cudnn.benchmark = True + channels_last victim (solver selection only; same arithmetic)'}
     net.cache_ori_cla = True                       # the unperturbed images' logits never change in the loop
     dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
     out['end_to_end_victim_cnn_cached_original_logits'] = {
@@ -314,6 +357,132 @@ def attack_bench(dev, iters=5):
                                           'PyTorch) + one multi-RHS pass over the inverted index'}
     out['batch_views'] = B
     out['unit'] = 'NeRFail-S iterations/s (batch of 8 views, 800x800, P=3)'
+    return out
+
+
+def _attack_inputs(dev, n_views, seed=0):
+    """Synthetic NeRFail-S inputs at full size: the 1.92 M-point set and each view's 640 000 query
+    points are unit-sphere-shell points (radius 1 +- 0.01); every view's [2,800,800,8] weight/index map is BUILT BY THE
+    PATH ITSELF (K8 nerfail_knn8_grid -> K9 nerfail_gauss_weight), exactly what create_index_and_dist + dist_to_weight
+    write; images are uint8-valued BGRA with alpha = 255 inside a centred disc; zero-init perturbation (AS:259-263)."""
+    from nerfail_amd.create_index_and_dist import index_and_dist
+    from nerfail_amd.GaussNet import create_gauss_w
+    P = 3
+    S = torch.from_numpy(synth.sphere_shell_points(P * H * W, seed=seed)).to(dev)
+    cw = create_gauss_w(dev, 0.02)
+    maps = []
+    for v in range(n_views):
+        Q = torch.from_numpy(synth.sphere_shell_points(H * W, seed=seed + 1 + v).reshape(H, W, 3)).to(dev)
+        maps.append(cw(index_and_dist(Q, S).unsqueeze(0))[0][0])
+    wi = torch.stack(maps)
+    ori = torch.from_numpy(synth.disc_alpha_image(n_views, H, W, seed=seed + 100)).to(dev)
+    s_init = torch.zeros((P, H, W, 4), device=dev)
+    s_init[..., 3] = torch.from_numpy(synth.disc_alpha_image(P, H, W, seed=seed + 200)[..., 3]).to(dev)
+    return wi, ori, s_init
+
+
+def cfg3_bench(dev, iters=20, n_views=16, batch=8):
+    """BASELINE.json configs[2]: the 20-iteration IGSM loop of attack_NeRFail_S.py (AS:278-392) through the 8-NN Gaussian
+    scatter over 16 views = 2 batches of 8, perturbation updated after every batch, stand-in 800x800 victim CNN."""
+    from nerfail_amd.GaussNet import gauss_net
+    from nerfail_amd.attack import nerfail_s_loop
+    t = time.time()
+    wi, ori, s_init = _attack_inputs(dev, n_views, seed=40)
+    torch.cuda.synchronize()
+    t_build = time.time() - t
+    torch.manual_seed(0)
+    victim = victim_cnn(8).to(dev).requires_grad_(False)
+    net = gauss_net(dev, 0.02, victim, 'my_model', epsilon=None)
+    net.cache_ori_cla = True
+    batches = [(wi[b:b + batch].contiguous(), ori[b:b + batch].contiguous()) for b in range(0, n_views, batch)]
+    label = torch.tensor(4, device=dev)
+    nerfail_s_loop(net, s_init, s_init, batches, label, 1)                  # warm-up: inverted indices, MIOpen plans
+    torch.cuda.synchronize()
+    t = time.time()
+    s = nerfail_s_loop(net, s_init, s_init, batches, label, iters)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    steps = iters * len(batches)
+    return {'iters_per_sec': steps / dt, 'ms_per_iter': dt / steps * 1e3, 'loop_seconds': dt, 'loop': '%d iterations x %d batches of %d views'
+            % (iters, len(batches), batch), 'map_build_seconds_16_views_knn8_plus_weights': t_build,
+            'moved_fraction': float((s[..., :3] != 0).float().mean()),
+            'note': 'one "iter" = one batch step (gauss_net forward, CE, backward, sign step); maps built by K8+K9 on '
+                    'synthetic shell points; original-image logits cached (identical results)'}
+
+
+def multi_gpu_legs(dev, world, rank, steps, nets, K):
+    """N > 1 only. (a) strong-scaling render: ONE view per step, its 640 000 rays cut into contiguous per-rank ranges
+    (sharding.render_shard; no collective). (b) NeRFail-S attack step, cfg5 shape: the 8 views of ONE batch split over
+    ranks, one all-reduce (C1, RCCL over xGMI) of the 30.72 MB perturbation gradient, identical sign step everywhere."""
+    from nerfail_amd import sharding
+    from nerfail_amd.GaussNet import gauss_net
+    from nerfail_amd.attack import nerfail_s_step
+    coarse, fine = nets
+    kw = dict(network_query_fn=None, perturb=0., N_importance=N_IMPORTANCE, network_fine=fine, N_samples=N_SAMPLES,
+              network_fn=coarse, white_bkgd=True, raw_noise_std=0.)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, n, warm=1):
+        for i in range(warm):
+            fn(i)
+        barrier()
+        t0 = time.time()
+        for i in range(n):
+            fn(warm + i)
+        barrier()
+        t = torch.tensor([time.time() - t0], device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    thetas = np.linspace(-180, 180, 41)[:-1]
+
+    def strong(i):
+        c2w = torch.from_numpy(synth.pose_spherical(float(thetas[i % len(thetas)]), -30., 4.)[:3, :4])
+        with torch.no_grad():
+            return sharding.render_shard(H, W, K, c2w, 2., 6., rank, world, chunk=H * W, **kw)
+    dt = timed(strong, steps)
+    out = {'render_strong': {'rays_per_sec': steps * H * W / dt, 'ms_per_view': dt / steps * 1e3, 'scaling': 'strong',
+                             'rays_per_rank': [hi - lo for lo, hi in sharding.shard_ranges(H * W, world)],
+                             'note': 'one 800x800 view per step, contiguous ray ranges per rank, no collective'}}
+
+    B = 8
+    wi, ori, s_init = _attack_inputs(dev, B, seed=60)
+    torch.manual_seed(0)
+    victim = victim_cnn(8).to(dev).requires_grad_(False)
+    net = gauss_net(dev, 0.02, victim, 'my_model', epsilon=None)
+    net.cache_ori_cla = True
+    label = torch.tensor(4, device=dev)
+    timing = {}
+    state = {'s': s_init.clone()}
+
+    def attack(i):
+        state['s'], _ = nerfail_s_step(net, state['s'], s_init, wi, ori, label, 2.0, 32.0, False, timing=timing)
+    attack(0)
+    timing.clear()
+    n_it = max(5, steps)
+    dt = timed(attack, n_it, warm=1)
+    ev = timing.get('allreduce_events', [])[1:]                     # (the first is the warm-up iteration inside timed)
+    ar_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+    nbytes = ev[0][2] if ev else 0
+    ar = float(np.median(ar_ms)) if ar_ms else None
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, torch.cuda.current_device()))
+    # all ranks must hold the identical perturbation after the loop (the property the sharding preserves)
+    chk = state['s'].double().sum().reshape(1).to(dev if dist.get_backend() == 'nccl' else 'cpu')
+    lo_, hi_ = chk.clone(), chk.clone()
+    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+    out['attack'] = {'iters_per_sec': n_it / dt, 'ms_per_iter': dt / n_it * 1e3, 'batch_views': B,
+                     'views_per_rank': [hi - lo for lo, hi in sharding.shard_ranges(B, world)],
+                     'allreduce_ms': ar, 'allreduce_bytes': nbytes, 'allreduce_backend': dist.get_backend(),
+                     'allreduce_bus_GBps': (2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9) if ar else None,
+                     'xgmi_per_link_peak_GBps': 153.0, 'ranks_seen': seen,
+                     'perturbation_identical_on_all_ranks': bool(float(lo_[0]) == float(hi_[0])),
+                     'note': 'NeRFail-S step (AS:304-392) end to end with the stand-in 800x800 victim CNN; bus GB/s = '
+                             '2(N-1)/N x bytes / time (ring-equivalent), to compare with one xGMI link'}
     return out
 
 
@@ -422,18 +591,17 @@ def main():
 
     # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes of this same command (corrected as
     # MI355X_MICROARCH.md prescribes); profiles/ travels with the repo, the counters cannot be read from inside bench.py
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))['kernels']
-        k = [v for n, v in pmc.items() if 'nerf_mlp_fwd_kernel' in n][0]
-        traffic = k['fetch_bytes_per_launch_corrected'] + k['write_bytes_per_launch']
-    except Exception:
-        pass
+    traffic, traffic_source = pmc_traffic('nerf_mlp_fwd_kernel')
     comp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in comp_events)
     comp_bytes = sum(b for _, _, b in comp_events)
     mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in mlp_events)
     mlp_samples = sum(n for _, _, n in mlp_events)
     achieved = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+
+    RN._mlp_points, RN._composite = orig_mlp, orig_comp
+    legs = None
+    if world > 1 and not args.no_attack:
+        legs = multi_gpu_legs(dev, world, rank, args.steps, (coarse, fine), K)
 
     if rank == 0:
         rays_total = world * args.steps * H * W
@@ -449,6 +617,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'nerf_mlp_fwd_kernel<8>', 'achieved': achieved,
                          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
                          'traffic': traffic, 'traffic_unit': 'HBM+IC bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
+                         'traffic_source': traffic_source,
                          'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
                          'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
             # the other roofline the north star asks for: achieved HBM rate of the compositing scan (K5 + K7)
@@ -462,12 +631,37 @@ def main():
                 line['train'] = train_bench(dev)
             if 'attack' in sections:
                 line['attack'] = attack_bench(dev)
+                line['attack']['cfg3_loop'] = cfg3_bench(dev)
             if 'knn' in sections:
                 line['knn'] = knn_bench(dev)
             if 'f16x3' in sections:
                 line['train_f16x3'] = train_bench(dev, precision='f16x3')
                 line['render_f16x3'] = render_f16x3_bench(dev)
                 line['render_f16x3']['speedup_vs_f32_kernel_this_run'] = line['render_f16x3']['rays_per_sec'] / line['value']
+        if legs is not None:
+            line.update(legs)
+        # BASELINE.json's metric string names three numbers: rays/s forward (value above), rays/s fwd+bwd, attack
+        # iterations/s. Each with its own roofline object, in one list the driver's parser keeps.
+        metrics = [{'metric': 'rays/sec (render, forward)', 'value': line['value'], 'unit': 'rays/s', 'n_gpus': world,
+                    'roofline': line['roofline']}]
+        if 'train' in line:
+            metrics.append({'metric': 'rays/sec (fwd+bwd)', 'value': line['train']['train_rays_per_sec_fwd_bwd'], 'unit': 'rays/s',
+                            'n_gpus': 1, 'roofline': line['train'].get('roofline'), 'note': line['train'].get('note')})
+        if 'attack' in line and 'gauss_path_deterministic' in line['attack']:
+            a = line['attack']
+            metrics.append({'metric': 'attack iters/sec (gauss path K10+K11+K12, batch of 8 views)', 'unit': 'iterations/s',
+                            'value': a['gauss_path_deterministic']['iters_per_sec'], 'n_gpus': 1,
+                            'roofline': a['gauss_path_deterministic']['roofline']})
+            metrics.append({'metric': 'attack iters/sec (end to end, stand-in victim CNN)', 'unit': 'iterations/s',
+                            'value': a['end_to_end_victim_cnn']['iters_per_sec'], 'n_gpus': 1, 'roofline': None,
+                            'note': 'MIOpen convolutions of the out-of-scope classifier dominate; see attack.*'})
+            if 'cfg3_loop' in a:
+                metrics.append({'metric': 'attack iters/sec (cfg3: 20 iterations x 16 views, K8-built maps)', 'unit': 'iterations/s',
+                                'value': a['cfg3_loop']['iters_per_sec'], 'n_gpus': 1, 'roofline': None})
+        elif 'attack' in line:
+            metrics.append({'metric': 'attack iters/sec (end to end, one batch of 8 views split over ranks + C1 all-reduce)',
+                            'unit': 'iterations/s', 'value': line['attack']['iters_per_sec'], 'n_gpus': world, 'roofline': None})
+        line['metrics'] = metrics
         # the CPU baseline runs LAST: its 256 OpenBLAS worker threads keep spinning for a while after the last sgemm and
         # starve the Python launch thread of whatever GPU section follows (seen as a 7x slower training section)
         line['cpu_baseline'] = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None

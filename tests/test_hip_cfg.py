@@ -94,24 +94,40 @@ def test_cfg3_full_size_loop_on_knn_built_maps(cfg3_scene):
     ori = T(synth.disc_alpha_image(16, H, W, seed=3))
     s0 = torch.zeros((P, H, W, 4), device=dev())
     s0[..., 3] = T(synth.disc_alpha_image(P, H, W, seed=4))[..., 3]              # zero init, alpha = base alpha (AS:259-263)
+    label = torch.tensor(4, device=dev())
+    batches = [(wi[b * B:(b + 1) * B].contiguous(), ori[b * B:(b + 1) * B].contiguous()) for b in range(2)]
+
+    def check(s):
+        assert torch.equal(s[..., 3], s0[..., 3])                                # alpha untouched
+        assert float((s[..., :3] - s0[..., :3]).abs().max()) <= 32.0
+        assert float(s[..., :3][s0[..., 3] == 0].abs().max()) == 0.0             # nothing outside the mask
+        assert float((s[..., :3] != 0).float().mean()) > 0.01                    # the gradient reached the point set
+        vals = torch.unique(s[..., :3])
+        assert torch.equal(vals, vals.round()) and float((vals % 2).abs().max()) == 0    # multiples of a = 2
+
+    # (1) a classifier made of deterministic torch ops (fixed-window average pool + matmul): everything between the
+    # perturbation and the loss is then reproducible, and so must be the whole loop, bit for bit
+    cls_w = T((np.random.RandomState(5).normal(size=(8, 48)) * 0.05).astype(np.float32))
+
+    class Pool(torch.nn.Module):
+        def forward(self, x):
+            return torch.nn.functional.avg_pool2d(x, 200).reshape(x.shape[0], -1) @ cls_w.t()
+    net = gauss_net(dev(), 0.02, Pool(), 'my_model', epsilon=None)
+    runs, losses = [], []
+    for rep in range(2):
+        runs.append(nerfail_s_loop(net, s0, s0, batches, label, 3, 2.0, 32.0, False,
+                                   on_iter=lambda it, b, s_, l: losses.append(float(l))))
+    assert torch.equal(runs[0], runs[1])                                         # deterministic backward: bitwise repeatable
+    assert losses[:6] == losses[6:] and all(np.isfinite(losses))
+    check(runs[0])
+
+    # (2) the 800x800 victim CNN of the bench (MIOpen convolutions: their algorithm choice, hence the last bits of the
+    # gradient, may change between calls - a sign can flip only where the gradient is at rounding level)
     torch.manual_seed(0)
     victim = bench.victim_cnn(8).to(dev()).requires_grad_(False)
     net = gauss_net(dev(), 0.02, victim, 'my_model', epsilon=None)
-    batches = [(wi[b * B:(b + 1) * B].contiguous(), ori[b * B:(b + 1) * B].contiguous()) for b in range(2)]
-    label = torch.tensor(4, device=dev())
-    losses = []
-    runs = []
-    for rep in range(2):
-        s = nerfail_s_loop(net, s0, s0, batches, label, 3, 2.0, 32.0, False,
-                           on_iter=lambda it, b, s_, l: losses.append(float(l)))
-        runs.append(s)
-    assert torch.equal(runs[0], runs[1])                                         # deterministic backward: bitwise repeatable
-    assert losses[:6] == losses[6:] and all(np.isfinite(losses))
-    s = runs[0]
-    assert torch.equal(s[..., 3], s0[..., 3])                                    # alpha untouched
-    assert float((s[..., :3] - s0[..., :3]).abs().max()) <= 32.0
-    assert float(s[..., :3][s0[..., 3] == 0].abs().max()) == 0.0                 # nothing outside the mask
-    moved = (s[..., :3] != 0).float().mean()
-    assert float(moved) > 0.01                                                   # the gradient reached the point set
-    vals = torch.unique(s[..., :3])
-    assert torch.equal(vals, vals.round()) and float((vals % 2).abs().max()) == 0    # multiples of a = 2
+    runs = [nerfail_s_loop(net, s0, s0, batches, label, 3, 2.0, 32.0, False) for rep in range(2)]
+    flips = float((runs[0] != runs[1]).float().mean())
+    print('cfg3 full size, victim CNN: fraction of perturbation elements that differ between two runs %.2e' % flips)
+    assert flips < 1e-3
+    check(runs[0])
