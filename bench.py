@@ -361,18 +361,21 @@ def attack_bench(dev, iters=5):
 
 
 def _attack_inputs(dev, n_views, seed=0):
-    """Synthetic NeRFail-S inputs at full size: the 1.92 M-point set and each view's 640 000 query
-    points are unit-sphere-shell points (radius 1 +- 0.01); every view's [2,800,800,8] weight/index map is BUILT BY THE
-    PATH ITSELF (K8 nerfail_knn8_grid -> K9 nerfail_gauss_weight), exactly what create_index_and_dist + dist_to_weight
-    write; images are uint8-valued BGRA with alpha = 255 inside a centred disc; zero-init perturbation (AS:259-263)."""
+    """Synthetic NeRFail-S inputs at full size. Geometry = the analytic `pts_max` of a rough unit
+    sphere (synth.sphere_view_points: hit pixels on the surface, miss pixels on the near plane, ARRAY ORDER = PIXEL ORDER
+    as in the real pipeline): the 1.92 M-point set is 3 base views (CI:57-61), each attack view's 640 000 query points
+    come from its own pose, and every view's [2,800,800,8] weight/index map is BUILT BY THE PATH ITSELF (K8
+    nerfail_knn8_grid -> K9 nerfail_gauss_weight), exactly what create_index_and_dist + dist_to_weight write. Images are
+    uint8-valued BGRA with alpha = 255 inside a centred disc (about the sphere's silhouette); zero-init perturbation
+    with alpha = base-view alpha (AS:259-263)."""
     from nerfail_amd.create_index_and_dist import index_and_dist
     from nerfail_amd.GaussNet import create_gauss_w
     P = 3
-    S = torch.from_numpy(synth.sphere_shell_points(P * H * W, seed=seed)).to(dev)
+    S = torch.from_numpy(np.stack([synth.sphere_view_points(H, W, th) for th in (-120., 0., 120.)]).reshape(-1, 3)).to(dev)
     cw = create_gauss_w(dev, 0.02)
     maps = []
     for v in range(n_views):
-        Q = torch.from_numpy(synth.sphere_shell_points(H * W, seed=seed + 1 + v).reshape(H, W, 3)).to(dev)
+        Q = torch.from_numpy(synth.sphere_view_points(H, W, -171. + 360. * ((v * 7 + seed) % 40) / 40.)).to(dev)
         maps.append(cw(index_and_dist(Q, S).unsqueeze(0))[0][0])
     wi = torch.stack(maps)
     ori = torch.from_numpy(synth.disc_alpha_image(n_views, H, W, seed=seed + 100)).to(dev)
@@ -407,7 +410,7 @@ def cfg3_bench(dev, iters=20, n_views=16, batch=8):
             % (iters, len(batches), batch), 'map_build_seconds_16_views_knn8_plus_weights': t_build,
             'moved_fraction': float((s[..., :3] != 0).float().mean()),
             'note': 'one "iter" = one batch step (gauss_net forward, CE, backward, sign step); maps built by K8+K9 on '
-                    'synthetic shell points; original-image logits cached (identical results)'}
+                    'the analytic sphere pts_max; original-image logits cached (identical results)'}
 
 
 def multi_gpu_legs(dev, world, rank, steps, nets, K):

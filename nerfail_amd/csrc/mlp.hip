@@ -22,6 +22,7 @@
 //   * alpha_linear (W->1) and rgb_linear (W/2->3) are too thin for a 32-wide MFMA tile: VALU dot
 //     products on the accumulator registers + one cross-half shuffle.
 // Bound: f32 MFMA (157 TFLOP/s dense on MI355X); algorithmic work 1 186 816 FLOP per sample (D8 W256).
+#include <stdlib.h>
 #include "mlp_layout.h"
 
 namespace nerfail {
@@ -119,18 +120,6 @@ __global__ void pack_heads_kernel(const float* __restrict__ aw, const float* __r
 }
 
 // ------------------------------------------------------------------------------------- device side
-struct MlpArgs {
-    const float* packed;
-    const float* pts;        // [M,3]      (NULL when xemb is given)
-    const float* viewdirs;   // [rays,3]
-    const float* xemb;       // [M,90] already embedded input, or NULL
-    float* raw;              // [M,4]
-    float* acts;             // training only: [tiles][TrainLayout::a_slots][64][16] activations for the backward
-    long M;
-    int spr;                 // samples per ray
-    MlpLayout lay;
-};
-
 template <int NT, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
     constexpr int OTV = NT / 2;
@@ -305,7 +294,17 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
     }
 }
 
+// Inference goes to the LDS-streaming kernel (mlp_lds.hip) when it covers the shape (even depth <= 8); the training
+// forward (activations saved) and the other shapes run the register-streamed kernel below. NERFAIL_FWD_KERNEL=reg
+// forces the latter (A/B timing, parity tests of both).
+static bool use_lds_kernel(const MlpArgs& a) {
+    static const int forced = [] { const char* e = getenv("NERFAIL_FWD_KERNEL"); return e ? (e[0] == 'r' ? 1 : 2) : 0; }();
+    if (forced == 1 || a.acts != nullptr) return false;
+    return !(a.lay.D & 1) && a.lay.D <= 8;
+}
+
 static int launch_mlp(const MlpArgs& a, int W, hipStream_t s) {
+    if (use_lds_kernel(a)) return launch_mlp_lds(a, W, s);
     const long ntiles = (a.M + 31) / 32;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -361,7 +360,7 @@ extern "C" int nerfail_mlp_pack(const nerfail_mlp_params* p, float* packed, void
         } else {
             d.w = p->views_w; d.b = p->views_b; d.out_f = W / 2; d.in_f = W + kDirCh; d.OT = OTV; d.h0 = 0; d.dir0 = W;
         }
-        d.total_w = (int)(L.b_off[l] - L.w_off[l]);
+        d.total_w = (int)L.w_count[l];
         d.w_off = L.w_off[l]; d.b_off = L.b_off[l];
     }
     pack_all_layers_kernel<<<dim3(64, (unsigned)tab.n), dim3(256), 0, s>>>(tab, packed);

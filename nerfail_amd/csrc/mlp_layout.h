@@ -22,12 +22,23 @@ __host__ __device__ inline int enc_channel(int s, int h, int bands) {
 // Channel of a 32-channel accumulator tile held in register r of lane half h (32x32 C/D layout).
 __host__ __device__ inline int acc_channel(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Packed f32 image (nerfail_mlp_pack), in 1 KB "pieces" of 256 floats:
+//   [0, w_total)        the WEIGHT STREAM: layer after layer in consumption order (pts_linears 0..D-1, feature_linear,
+//                       views_linears), each layer [quad][out-tile][lane][4] = A fragments, one piece per (quad, tile);
+//                       padded at the end to a whole number of ring groups (4*NT pieces) - the LDS-streaming forward
+//                       kernel (mlp_lds.hip) copies exactly this range through its ring, piece after piece;
+//   [b_off[0], total)   the CONSTANT area: one piece per layer bias ([OT][2][16], rest of the piece unused), then the
+//                       alpha and rgb heads, each padded to whole pieces; copied once per workgroup into LDS.
 struct MlpLayout {
     int NT, D, skip;
     unsigned w_off[NERFAIL_MAX_DEPTH + 2];   // [0..D-1] pts layers, [D] feature, [D+1] views
     unsigned b_off[NERFAIL_MAX_DEPTH + 2];
+    unsigned w_count[NERFAIL_MAX_DEPTH + 2]; // floats of layer l's weights (quads * OT * 256)
     unsigned alpha_off, rgb_off, total;
+    unsigned w_total;                        // floats of the weight stream incl. its end padding
+    unsigned stream_pad;                     // padding pieces after the views weights
 };
+constexpr int kPiece = 256;                  // floats per piece (one wave-wide 16-byte access = 1 KB)
 
 static inline bool layer_has_emb(int l, int skip) { return l == 0 || (skip >= 0 && l == skip + 1); }
 
@@ -44,11 +55,15 @@ static bool make_layout(int D, int W, int skip, MlpLayout& L) {
         if (l <= D - 1 && layer_has_emb(l, skip)) quads += kEmbQuads;
         if (l > 0) quads += NT * 4;
         if (l == D + 1) quads += kDirQuads;
-        L.w_off[l] = off; off += (unsigned)quads * OT * 256;
-        L.b_off[l] = off; off += (unsigned)OT * 32;
+        L.w_off[l] = off; L.w_count[l] = (unsigned)quads * OT * 256; off += L.w_count[l];
     }
-    L.alpha_off = off; off += (unsigned)NT * 32 + 4;
-    L.rgb_off = off; off += 3u * OTV * 32 + 4;
+    const unsigned group = 4u * NT * kPiece;                  // every part but the last is a multiple of this already
+    const unsigned pad = (group - off % group) % group;
+    L.stream_pad = pad / kPiece; off += pad; L.w_total = off;
+    for (int l = 0; l <= D + 1; ++l) { L.b_off[l] = off; off += kPiece; }
+    auto up = [](unsigned n) { return (n + kPiece - 1) / kPiece * kPiece; };
+    L.alpha_off = off; off += up((unsigned)NT * 32 + 4);
+    L.rgb_off = off; off += up(3u * OTV * 32 + 4);
     L.total = off;
     return true;
 }
@@ -82,6 +97,68 @@ static inline TrainLayout make_train_layout(int D, int W) {
     t.a_E = 0; t.a_V = 2; t.a_H1 = 3; t.a_F = 3 + D * t.NT; t.a_HV = t.a_F + t.NT; t.a_MASK = t.a_HV + t.OTV; t.a_slots = t.a_MASK + train_mask_slots(D);
     t.z_Z0 = 0; t.z_ZF = D * t.NT; t.z_ZV = t.z_ZF + t.NT; t.z_ZR = t.z_ZV + t.OTV; t.z_slots = t.z_ZR + 1;
     return t;
+}
+
+// arguments of the fused forward kernels (mlp.hip: register-streamed, also the training forward; mlp_lds.hip: LDS ring)
+struct MlpArgs {
+    const float* packed;
+    const float* pts;        // [M,3]      (NULL when xemb is given)
+    const float* viewdirs;   // [rays,3]
+    const float* xemb;       // [M,90] already embedded input, or NULL
+    float* raw;              // [M,4]
+    float* acts;             // training only: [tiles][TrainLayout::a_slots][64][16] activations for the backward
+    long M;
+    int spr;                 // samples per ray
+    MlpLayout lay;
+};
+int launch_mlp_lds(const MlpArgs& a, int W, hipStream_t s);      // mlp_lds.hip; NERFAIL_EINVAL when the shape is not covered
+
+// B operands of the two encoding parts of sample s for lane half h (k-step st <-> channel enc_channel(st, h, bands)):
+// computed in registers from the raw point / view direction (one shared double-precision argument reduction per
+// coordinate, SinCosBands), or gathered from an already embedded input row (NeRF.forward's contract).
+__device__ __forceinline__ void encode_sample(const MlpArgs& a, long s, int h, float (&emb)[4 * kEmbQuads], float (&demb)[4 * kDirQuads]) {
+    if (a.xemb == nullptr) {
+        const float px[3] = {a.pts[3 * s], a.pts[3 * s + 1], a.pts[3 * s + 2]};
+        const float* vd = a.viewdirs + 3 * (s / a.spr);
+        const float vx[3] = {vd[0], vd[1], vd[2]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const SinCosBands sc(px[d]);
+#pragma unroll
+            for (int f = 0; f < 10; ++f) {
+                float sn, cs;
+                sc.band(f, sn, cs);
+                emb[3 * f + d] = h ? cs : sn;
+            }
+        }
+        emb[30] = h ? px[1] : px[0];
+        emb[31] = h ? 0.f : px[2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const SinCosBands sc(vx[d]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float sn, cs;
+                sc.band(f, sn, cs);
+                demb[3 * f + d] = h ? cs : sn;
+            }
+        }
+        demb[12] = h ? vx[1] : vx[0];
+        demb[13] = h ? 0.f : vx[2];
+        demb[14] = 0.f; demb[15] = 0.f;
+    } else {
+        const float* x = a.xemb + (kPtsCh + kDirCh) * s;
+#pragma unroll
+        for (int st = 0; st < 4 * kEmbQuads; ++st) {
+            const int c = enc_channel(st, h, 10);
+            emb[st] = c >= 0 ? x[c] : 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < 4 * kDirQuads; ++st) {
+            const int c = enc_channel(st, h, 4);
+            demb[st] = c >= 0 ? x[kPtsCh + c] : 0.f;
+        }
+    }
 }
 
 // transposed-weight image for the backward-data pass: [layer 1..D-1, feature, views][quad][in-tile][lane][4]

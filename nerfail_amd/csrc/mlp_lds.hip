@@ -1,0 +1,362 @@
+// K3 + K4, inference form: fused positional encoding + NeRF MLP forward on the exact-f32 matrix cores with the weight
+// stream staged ONCE per workgroup through an LDS ring (run_nerf.py:37-51, run_nerf_helpers.py:15-50, :100-123).
+//
+// Same arithmetic and the same register-resident activation scheme as mlp.hip (every layer transposed, the 32x32
+// accumulator of one layer is the B operand of the next; v_mfma_f32_32x32x2_f32 = exact f32 FMA chain; one wave per
+// SIMD, 32 samples x all channels per wave). What differs is how the A operands (weights) reach the MFMAs:
+//   * mlp.hip: every wave loads every weight fragment itself, global -> VGPR, one quad ahead: 4 x 2.4 MB per CU and
+//     tile round from L2, a 64-register ring, 70 spilled registers; measured cost of that delivery: 6.5 % + 1 %.
+//   * here: the 4 waves of a workgroup share ONE copy of the stream. The packed image's weight range is copied piece by
+//     piece (1 KB = one wave-wide 16-byte access = the A fragments of one (quad, out-tile)) by LDS-DMA
+//     (global_load_lds_dwordx4: no VGPRs, no VALU) into a ring of RP pieces cut into S groups; wave w moves pieces
+//     w, w+4, ... of every group. A group becomes readable at ONE s_barrier per group (after each wave's counted
+//     s_waitcnt vmcnt, which leaves the S-2 younger groups in flight); the slot freed at that barrier is refilled at
+//     once, the refill's DMA instructions interleaved with the following MFMAs. The stream never stops: it runs across
+//     layer and tile boundaries (the ring does not know about layers), so no part of a layer starts on an exposed load.
+//     Barrier positions are compile-time (every layer part is a whole number of groups; the image is padded for it).
+//   * the MFMA order inside a quad is tile-major (4 k-steps of one out-tile back to back: the dependent-accumulator
+//     latency of this instruction equals its issue time), so a fragment lives for 4 MFMAs and the next step's
+//     fragments are read from LDS (ds_read_b128, conflict-free) while the current step's 16 MFMAs run: 32 VGPRs of
+//     fragments instead of 64, no spills.
+//   * ReLU is applied to a B operand in place right before its quad uses it (hidden between MFMAs) and the two
+//     activation arrays swap roles from layer to layer: no copy, no ReLU pass at a layer boundary.
+//   * biases and the two thin heads live in a constant LDS area loaded once per workgroup.
+// Bound: f32 MFMA (157.3 TFLOP/s dense); 1 186 816 FLOP per sample (D8 W256). LDS: 16*NT KB ring + 14 KB constants + 16 KB parked operands.
+#include "mlp_layout.h"
+
+namespace nerfail {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+
+#ifndef NF_LDS_GPM
+#define NF_LDS_GPM 4        // pieces per ring group = NF_LDS_GPM * NT (4: one barrier per 4 quads of a W-wide layer)
+#endif
+
+template <int N> __device__ __forceinline__ void lds_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ f32x4 lds_read4(const float* p) { return *(lds_cf4*)p; }
+
+template <int NT>
+struct LdsCfg {
+    static constexpr int HS = NT >= 4 ? 4 : NT;                 // pieces (= out tiles) per step at full width
+    static constexpr int GP = NF_LDS_GPM * NT;                  // pieces per group
+    static constexpr int RP = 16 * NT;                          // ring pieces (128 KB at W = 256)
+    static constexpr int S = RP / GP;                           // groups in the ring
+    static constexpr int GPW = GP / 4;                          // LDS-DMA instructions per wave and group
+    static constexpr int kViewsPieces = (4 * NT + kDirQuads) * (NT / 2);
+    static constexpr int kStreamPad = (4 * NT - kViewsPieces % (4 * NT)) % (4 * NT);   // = MlpLayout::stream_pad
+    static constexpr int kAlphaFloats = (NT * 32 + 4 + kPiece - 1) / kPiece * kPiece;
+    static constexpr int kRgbFloats = (3 * (NT / 2) * 32 + 4 + kPiece - 1) / kPiece * kPiece;
+    static constexpr int kMaxDepth = 8;                         // deeper nets run on the register-streamed kernel (mlp.hip)
+    static constexpr int kConstMax = (kMaxDepth + 2) * kPiece + kAlphaFloats + kRgbFloats;
+    static constexpr int kParkFloats = 4 * 64 * 4 * kDirQuads;  // the 16 view-direction operands of every lane, parked
+    static_assert(GP % 4 == 0 && RP % GP == 0 && S >= 3, "ring geometry");
+    static_assert((S - 2) * GPW <= 48, "vmcnt is a 6-bit counter");
+};
+
+// The weight stream of one workgroup. Every member but fr / gsrc / rl is wave-uniform (SGPRs).
+template <int NT>
+struct WRing {
+    using C = LdsCfg<NT>;
+    const float* gsrc;       // packed + lane*4: this lane's 16 bytes of stream piece 0
+    float* ring;             // LDS ring base
+    const float* rl;         // ring + lane*4
+    int total;               // stream length in pieces (multiple of GP)
+    int src;                 // next group's first source piece
+    int slot;                // ring group the next refill goes to
+    int rd;                  // ring piece the next step reads
+    int wave;
+    f32x4 fr[C::HS];         // fragments of the NEXT step (always C::HS pieces from rd; a narrower step uses the first ones)
+
+    __device__ __forceinline__ void dma(int i) const {           // this wave's i-th piece of the group being refilled
+        const int piece = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + piece) * kPiece),
+                                         (lds_void_t*)(ring + (slot * C::GP + piece) * kPiece), 16, 0, 0);
+    }
+    __device__ __forceinline__ void group_issued() {
+        src += C::GP;
+        if (src >= total) src = 0;
+        slot = (slot + 1 == C::S) ? 0 : slot + 1;
+    }
+    // Group boundary: every wave's pieces of the next group have landed (counted wait: the S-2 younger groups stay
+    // in flight), every wave's reads of the group just finished have returned -> one barrier makes the first
+    // readable for all and the second's slot free for all.
+    __device__ __forceinline__ void boundary() const {
+        lds_wait_vmcnt<(C::S - 2) * C::GPW>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void prefetch() {
+#pragma unroll
+        for (int t = 0; t < C::HS; ++t) fr[t] = lds_read4(rl + (rd + t) * kPiece);
+    }
+    __device__ __forceinline__ void start() {                   // S-1 groups in flight, group 0 readable, ring full
+#pragma unroll
+        for (int g = 0; g < C::S - 1; ++g) {
+#pragma unroll
+            for (int i = 0; i < C::GPW; ++i) dma(i);
+            group_issued();
+        }
+        boundary();
+#pragma unroll
+        for (int i = 0; i < C::GPW; ++i) dma(i);
+        group_issued();
+        prefetch();
+    }
+    // One step: consume HSP pieces (out tiles) x 4 k-steps; mf(t, e, a) issues the MFMA of tile t, k-step e with A
+    // operand a. SYNC: this step ends a group - cross the boundary BEFORE prefetching the next step's fragments (they
+    // belong to the next group) and refill the freed slot behind the first MFMAs.
+    // The schedule is pinned with sched_barrier(0): left alone, hipcc sinks the prefetch next to its use (every step then
+    // starts on an exposed ds_read), hoists a whole layer's lazy ReLUs to the front (259 spilled registers) and puts all
+    // refill DMAs in front of the MFMAs. The prefetch sits BEHIND the first tile's 4 MFMAs: hipcc answers the first use of
+    // `cur` with s_waitcnt lgkmcnt(0), which is free only while the reads of the NEXT step have not been issued yet.
+    template <int HSP, bool SYNC, class PRE, class MF>
+    __device__ __forceinline__ void step(PRE&& pre, MF&& mf) {
+        f32x4 cur[HSP];
+#pragma unroll
+        for (int t = 0; t < HSP; ++t) cur[t] = fr[t];
+        rd += HSP;
+        if (rd >= C::RP) rd = 0;
+        if (SYNC) boundary();
+        __builtin_amdgcn_sched_barrier(0);
+        pre();
+        int k = 0;
+#pragma unroll
+        for (int t = 0; t < HSP; ++t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mf(t, e, cur[t][e]);
+                if (SYNC && k < C::GPW) {        // one refill DMA behind each of the first MFMAs
+                    dma(k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ++k;
+            }
+            if (t == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (SYNC) {
+#pragma unroll
+            for (int i = 4 * HSP; i < C::GPW; ++i) dma(i);
+            group_issued();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int HSP, bool SYNC>
+    __device__ __forceinline__ void skip() {                     // padding pieces: no MFMAs
+        rd += HSP;
+        if (rd >= C::RP) rd = 0;
+        if (SYNC) {
+            boundary();
+#pragma unroll
+            for (int i = 0; i < C::GPW; ++i) dma(i);
+            group_issued();
+        }
+        prefetch();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+// One part of a layer: NQ quads of 4 k-steps over OT out tiles, then PAD padding pieces. bsel(q, e) yields the B operand
+// of k-step 4q+e; pre(q) runs before quad q (the lazy ReLU of the previous layer's output, in place on its 4 registers).
+template <int NT, int OT, int NQ, int PAD, int NIN, class Pre, class BSel>
+__device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Pre pre, BSel bsel) {
+    using C = LdsCfg<NT>;
+    constexpr int HSP = OT >= 4 ? 4 : OT, SPQ = OT / HSP;
+    static_assert((NQ * OT + PAD) % C::GP == 0, "a part is a whole number of ring groups");
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int sp = 0; sp < SPQ; ++sp) {
+            const int done = (q * SPQ + sp + 1) * HSP;
+            auto mf = [&](int t, int e, float a) {
+                acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsel(q, e), acc[sp * HSP + t], 0, 0, 0);
+            };
+            auto pr = [&]() { if (sp == 0) pre(q); };
+            if (done % C::GP == 0) st.template step<HSP, true>(pr, mf);
+            else st.template step<HSP, false>(pr, mf);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PAD / HSP; ++p) {
+        const int done = NQ * OT + (p + 1) * HSP;
+        if (done % C::GP == 0) st.template skip<HSP, true>();
+        else st.template skip<HSP, false>();
+    }
+}
+
+// max(x, 0) as ONE integer instruction on the bit pattern (negative floats are negative integers; -0 -> +0). fmaxf costs
+// two: hipcc first canonicalises an accumulator value (v_max x, x) before the IEEE-mode v_max with 0.
+__device__ __forceinline__ float relu_bits(float x) {
+    const int i = __float_as_int(x);
+    return __int_as_float(i > 0 ? i : 0);
+}
+
+// dot product of a thin head's weights (LDS, accumulator order [OT][2][16]) with relu(x): VALU + one cross-half shuffle.
+// One tile at a time (sched_barrier): left alone, hipcc reads all 128 accumulators into VGPRs first and the register
+// allocator answers by spilling the positional encodings across the whole layer loop.
+template <int OT, int NIN>
+__device__ __forceinline__ float lds_head(const f32x16 (&x)[NIN], const float* w, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 wv = lds_read4(w + (t * 2 + h) * 16 + 4 * r4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(wv[e], relu_bits(x[t][4 * r4 + e]), s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return s + __shfl_xor(s, 32, 64);
+}
+
+// SKIP: where the skip connection's extra part is compiled in: 0 nowhere, 1 first / 2 second layer of a pair.
+template <int NT, int SKIP>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
+    using C = LdsCfg<NT>;
+    constexpr int OTV = NT / 2;
+    // ONE object (a second __shared__ array beside an LDS-DMA target makes hipcc drain vmcnt before LDS reads). Constants
+    // first: their addresses are then 'lane part + immediate offset' (16-bit ds offsets) instead of one hoisted - and
+    // spilled - VGPR per bias tile.
+    __shared__ __attribute__((aligned(16))) float smem[C::kConstMax + C::kParkFloats + C::RP * kPiece];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const MlpLayout& L = a.lay;
+    float* const cst = smem;
+    float* const park = smem + C::kConstMax + wave * (64 * 4 * kDirQuads) + lane * 4;
+    float* const ring0 = smem + C::kConstMax + C::kParkFloats;
+    {   // constant area: biases (one piece per layer), alpha head, rgb head
+        const int n = (int)(L.total - L.b_off[0]);
+        const float* __restrict__ g = a.packed + L.b_off[0];
+        for (int i = tid * 4; i < n; i += 1024) *reinterpret_cast<f32x4*>(cst + i) = *reinterpret_cast<const f32x4*>(g + i);
+    }
+    __syncthreads();
+    const float* const c_alpha = cst + (L.alpha_off - L.b_off[0]);
+    const float* const c_rgb = cst + (L.rgb_off - L.b_off[0]);
+
+    WRing<NT> st;
+    st.gsrc = a.packed + lane * 4; st.ring = ring0; st.rl = ring0 + lane * 4;
+    st.total = (int)(L.w_total / kPiece); st.src = 0; st.slot = 0; st.rd = 0; st.wave = wave;
+    st.start();
+
+    // Two activation arrays swap roles from layer to layer (no copies, no ReLU pass). A layer's bias is written into
+    // its output array while that array is still the INPUT of the layer before: tile k is dead once that layer has
+    // consumed its quads 4k..4k+3, so the 4 LDS reads + 16 accumulator writes of a bias tile hide between its MFMAs
+    // instead of standing in front of the next layer (bias loads were 1 % of the register-streamed kernel).
+    f32x16 P[NT], Q[NT];
+    auto bias_tile = [&](f32x16 (&dst)[NT], int l, int t) {                              // dst[t] = bias of layer l, tile t
+        const float* p = cst + l * kPiece + (t * 2 + h) * 16;
+        const f32x4 v0 = lds_read4(p), v1 = lds_read4(p + 4), v2 = lds_read4(p + 8), v3 = lds_read4(p + 12);
+        dst[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
+                          v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+    };
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias_tile(P, 0, t);                                     // later rounds: written by the views layer
+
+    const long ntiles = (a.M + 31) / 32;
+    const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);
+    for (long rnd = 0; rnd < nrounds; ++rnd) {
+        // every wave of the workgroup walks the whole stream every round (it moves a quarter of it): a wave without a
+        // tile of its own recomputes the last tile and stores nothing
+        const long tile_own = (rnd * gridDim.x + blockIdx.x) * 4 + wave;
+        const long tile = tile_own < ntiles ? tile_own : ntiles - 1;
+        const long sraw = tile * 32 + j;
+        const long s = sraw < a.M ? sraw : a.M - 1;
+
+        float emb[4 * kEmbQuads], demb[4 * kDirQuads];
+        encode_sample(a, s, h, emb, demb);
+        auto b_emb = [&](int q, int e) { return emb[4 * q + e]; };
+        // the view-direction operands are needed once, 9 layers from here: parked in LDS meanwhile (kept in registers
+        // they were spilled to scratch, and a scratch reload drains the LDS-DMA queue: vmcnt retires in order)
+#pragma unroll
+        for (int k = 0; k < kDirQuads; ++k)
+            *reinterpret_cast<f32x4*>(park + k * 256) = (f32x4){demb[4 * k], demb[4 * k + 1], demb[4 * k + 2], demb[4 * k + 3]};
+
+        // layer 0: 63 -> W into P (its bias is already there); Q (dead) receives the bias of layer 1 meanwhile
+        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); }, b_emb);
+
+        // pts_linears[l] (l < D) / feature_linear (l == D): out += W_l relu(in). While it runs, `in` receives the bias of
+        // layer l+1 tile by tile as its tiles die (for l == D that is the views layer: its W/2 channels use the first
+        // tiles, the others get unused padding of the piece).
+        float alpha = 0.f;
+        auto layer = [&](f32x16 (&in)[NT], f32x16 (&out)[NT], int l, bool may_skip, bool may_be_last) {
+            if (may_be_last && l == L.D) alpha = lds_head<NT>(in, c_alpha, h) + c_alpha[NT * 32];   // alpha_linear on relu(h) (RH:110)
+            if (may_skip && l == L.skip + 1)                                              // h = cat([input_pts, h]) (RH:106-107)
+                lds_part<NT, NT, kEmbQuads, 0>(st, out, [](int) {}, b_emb);
+            lds_part<NT, NT, 4 * NT, 0>(st, out,
+                [&](int q) {
+                    if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)                                           // lazy ReLU of quad q's 4 B registers
+                        in[q >> 2][4 * (q & 3) + e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);
+                },
+                [&](int q, int e) { return in[q >> 2][4 * (q & 3) + e]; });
+            bias_tile(in, l + 1, NT - 1);
+        };
+#pragma unroll 1
+        for (int l = 1; l < L.D; l += 2) {                                                // D is even (host check): whole pairs
+            layer(P, Q, l, SKIP == 1, false);
+            layer(Q, P, l + 1, SKIP == 2, true);
+        }
+        // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q's first tiles (RH:112-116; its ReLU is applied by
+        // the rgb head); P, its input, receives the bias of the NEXT tile's layer 0 as it dies
+        lds_part<NT, OTV, 4 * NT, 0>(st, Q,
+            [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(P, 0, (q >> 2) - 1); },
+            [&](int q, int e) { return P[q >> 2][4 * (q & 3) + e]; });
+        bias_tile(P, 0, NT - 1);
+        f32x4 dq[kDirQuads];
+#pragma unroll
+        for (int k = 0; k < kDirQuads; ++k) dq[k] = lds_read4(park + k * 256);
+        lds_part<NT, OTV, kDirQuads, C::kStreamPad>(st, Q, [](int) {}, [&](int q, int e) { return dq[q][e]; });
+        float rgb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)                                                       // rgb_linear: W/2 -> 3 (RH:118)
+            rgb[c] = lds_head<OTV>(Q, c_rgb + c * OTV * 32, h) + c_rgb[3 * OTV * 32 + c];
+        if (h == 0 && sraw < a.M && tile_own < ntiles)
+            reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);
+    }
+    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight when the workgroup's LDS is released
+}
+
+template <int NT>
+static int launch_lds(const MlpArgs& a, unsigned blocks, hipStream_t s) {
+    using C = LdsCfg<NT>;
+    if ((int)a.lay.stream_pad != C::kStreamPad || a.lay.w_total / kPiece < (unsigned)C::GP || (a.lay.w_total / kPiece) % C::GP != 0 ||
+        a.lay.total - a.lay.b_off[0] > (unsigned)C::kConstMax) {
+        set_error("nerf_mlp_fwd_lds_kernel: packed layout does not match the ring geometry");
+        return NERFAIL_EINVAL;
+    }
+    if ((a.lay.D & 1) || a.lay.D > C::kMaxDepth) { set_error("nerf_mlp_fwd_lds_kernel: depth not covered"); return NERFAIL_EINVAL; }
+    const int skip_layer = a.lay.skip >= 0 ? a.lay.skip + 1 : -1;                         // layer that takes the extra part
+    if (skip_layer < 0) nerf_mlp_fwd_lds_kernel<NT, 0><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    else if (skip_layer & 1) nerf_mlp_fwd_lds_kernel<NT, 1><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    else nerf_mlp_fwd_lds_kernel<NT, 2><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    NF_LAUNCHED("nerf_mlp_fwd_lds_kernel");
+    return NERFAIL_OK;
+}
+
+int launch_mlp_lds(const MlpArgs& a, int W, hipStream_t s) {
+    const long ntiles = (a.M + 31) / 32;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > cus) blocks = cus;      // persistent: one 4-wave workgroup per CU, one wave per SIMD
+    switch (W) {
+        case 256: return launch_lds<8>(a, (unsigned)blocks, s);
+        case 128: return launch_lds<4>(a, (unsigned)blocks, s);
+        case 64: return launch_lds<2>(a, (unsigned)blocks, s);
+        default: set_error("nerfail_mlp_fwd: unsupported W"); return NERFAIL_EINVAL;
+    }
+}
+
+}  // namespace nerfail

@@ -94,3 +94,27 @@ def disc_alpha_image(B, H, W, seed=0, radius_frac=0.375):
     inside = ((yy - H / 2 + .5) ** 2 + (xx - W / 2 + .5) ** 2) <= (radius_frac * H) ** 2
     img[..., 3] = np.where(inside, 255.0, 0.0)[None]
     return img
+
+
+def sphere_view_points(H, W, theta, phi=-30.0, radius=4.0, obj_radius=1.0, rough=0.01, near=2.0):
+    """Analytic `pts_max` [H,W,3] of a rough unit sphere seen from pose_spherical(theta, phi, radius) (NC:418-423
+    semantics): a pixel whose ray hits the sphere gets its first intersection point (surface radius 1 +- rough, a
+    deterministic per-pixel hash), a pixel that misses gets the near-plane point o + near*d (argmax of all-zero weights is
+    sample 0). Unlike sphere_shell_points the ARRAY ORDER is the pixel order, as in the real pipeline: neighbouring
+    pixels are neighbouring 3-D points, so an 8-NN map built on these has the index locality of a real scene."""
+    focal, K = lego_intrinsics(H, W)
+    c2w = pose_spherical(theta, phi, radius)[:3, :4].astype(np.float64)
+    jj, ii = np.mgrid[0:H, 0:W]
+    dirs = np.stack([(ii - K[0][2]) / K[0][0], -(jj - K[1][2]) / K[1][1], -np.ones_like(ii, dtype=np.float64)], -1)
+    d = (dirs[..., None, :] * c2w[:3, :3]).sum(-1)
+    o = c2w[:3, 3]
+    pix = (jj * W + ii).astype(np.uint64)
+    hsh = ((pix * np.uint64(2654435761) + np.uint64(int(abs(theta) * 1000) + 12345)) % np.uint64(1 << 20)).astype(np.float64) / (1 << 20)
+    r = obj_radius * (1.0 + rough * (2.0 * hsh - 1.0))
+    a = (d * d).sum(-1)
+    b = 2.0 * (d * o).sum(-1)
+    c = (o * o).sum() - r * r
+    disc = b * b - 4 * a * c
+    hit = disc > 0
+    t = np.where(hit, (-b - np.sqrt(np.where(hit, disc, 0.0))) / (2 * a), near)
+    return (o + d * t[..., None]).astype(np.float32)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_without_gpu():
     from nerfail_amd import _lib
     lib = _lib.load()
-    assert lib.nerfail_mlp_packed_floats(8, 256, 4) == 597000
+    assert lib.nerfail_mlp_packed_floats(8, 256, 4) == 601600     # 2320 + 16 pad weight pieces, 10 bias pieces, 2 + 2 head pieces
     assert lib.nerfail_mlp_packed_floats(4, 64, 4) == lib.nerfail_mlp_packed_floats(4, 64, -1)
     assert lib.nerfail_mlp_packed_floats(8, 100, 4) == 0            # unsupported width
     assert lib.nerfail_composite(None, None, None, None, 5, 0, 0, None, None, None, None, None, None, None, None) == 1
