@@ -21,7 +21,7 @@
 //   * ReLU is applied to a B operand in place right before its quad uses it (hidden between MFMAs) and the two
 //     activation arrays swap roles from layer to layer: no copy, no ReLU pass at a layer boundary.
 //   * biases and the two thin heads live in a constant LDS area loaded once per workgroup.
-// Bound: f32 MFMA (157.3 TFLOP/s dense); 1 186 816 FLOP per sample (D8 W256). LDS: 16*NT KB ring + 14 KB constants + 16 KB parked operands.
+// Bound: f32 MFMA (157.3 TFLOP/s dense); 1 186 816 FLOP per sample (D8 W256). LDS: 12*NT KB ring + 14 KB constants + 48 KB parked operands.
 #include "mlp_layout.h"
 
 namespace nerfail {
@@ -41,7 +41,7 @@ template <int NT>
 struct LdsCfg {
     static constexpr int HS = NT >= 4 ? 4 : NT;                 // pieces (= out tiles) per step at full width
     static constexpr int GP = NF_LDS_GPM * NT;                  // pieces per group
-    static constexpr int RP = 16 * NT;                          // ring pieces (128 KB at W = 256)
+    static constexpr int RP = 12 * NT;                          // ring pieces (96 KB at W = 256: 3 groups of 32)
     static constexpr int S = RP / GP;                           // groups in the ring
     static constexpr int GPW = GP / 4;                          // LDS-DMA instructions per wave and group
     static constexpr int kViewsPieces = (4 * NT + kDirQuads) * (NT / 2);
@@ -50,9 +50,11 @@ struct LdsCfg {
     static constexpr int kRgbFloats = (3 * (NT / 2) * 32 + 4 + kPiece - 1) / kPiece * kPiece;
     static constexpr int kMaxDepth = 8;                         // deeper nets run on the register-streamed kernel (mlp.hip)
     static constexpr int kConstMax = (kMaxDepth + 2) * kPiece + kAlphaFloats + kRgbFloats;
-    static constexpr int kParkFloats = 4 * 64 * 4 * kDirQuads;  // the 16 view-direction operands of every lane, parked
+    static constexpr int kParkQuads = kEmbQuads + kDirQuads;    // the 32 + 16 encoding operands of every lane, parked in LDS
+    static constexpr int kParkFloats = 4 * 64 * 4 * kParkQuads;
     static_assert(GP % 4 == 0 && RP % GP == 0 && S >= 3, "ring geometry");
     static_assert((S - 2) * GPW <= 48, "vmcnt is a 6-bit counter");
+    static_assert(GPW <= 8 && (GPW % 4 == 0 || GPW < 4), "dma() covers 8 pieces per wave and group, in blocks of 4");
 };
 
 // The weight stream of one workgroup. Every member but fr / gsrc / rl is wave-uniform (SGPRs).
@@ -69,10 +71,23 @@ struct WRing {
     int wave;
     f32x4 fr[C::HS];         // fragments of the NEXT step (always C::HS pieces from rd; a narrower step uses the first ones)
 
-    __device__ __forceinline__ void dma(int i) const {           // this wave's i-th piece of the group being refilled
-        const int piece = wave + 4 * i;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + piece) * kPiece),
-                                         (lds_void_t*)(ring + (slot * C::GP + piece) * kPiece), 16, 0, 0);
+    // This wave's i-th piece of the group being refilled. A wave moves GPW CONSECUTIVE pieces (consecutive in the image
+    // and in the ring), so one address pair serves four of them through the instruction's immediate offset (applied to
+    // the global AND the LDS address): per piece no address arithmetic at all - behind an MFMA that matters, the issue
+    // of an LDS-DMA plus five scalar and one 64-bit vector instruction did not fit into the 64 cycles of its shadow.
+    template <int I>
+    __device__ __forceinline__ void dma_at() const {
+        constexpr int B4 = I / 4;                                // which block of 4 pieces (one base each)
+        const int first = wave * C::GPW + 4 * B4;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + first) * kPiece),
+                                         (lds_void_t*)(ring + (slot * C::GP + first) * kPiece), 16, (I % 4) * kPiece * 4, 0);
+    }
+    __device__ __forceinline__ void dma(int i) const {           // i is a constant after unrolling
+        switch (i) {
+            case 0: dma_at<0>(); break;   case 1: dma_at<1>(); break;   case 2: dma_at<2>(); break;   case 3: dma_at<3>(); break;
+            case 4: dma_at<4>(); break;   case 5: dma_at<5>(); break;   case 6: dma_at<6>(); break;   case 7: dma_at<7>(); break;
+            default: break;
+        }
     }
     __device__ __forceinline__ void group_issued() {
         src += C::GP;
@@ -112,8 +127,10 @@ struct WRing {
     // starts on an exposed ds_read), hoists a whole layer's lazy ReLUs to the front (259 spilled registers) and puts all
     // refill DMAs in front of the MFMAs. The prefetch sits BEHIND the first tile's 4 MFMAs: hipcc answers the first use of
     // `cur` with s_waitcnt lgkmcnt(0), which is free only while the reads of the NEXT step have not been issued yet.
-    template <int HSP, bool SYNC, class PRE, class MF>
-    __device__ __forceinline__ void step(PRE&& pre, MF&& mf) {
+    // pre() runs before the MFMAs (work the step itself needs), mid() behind the first tile's MFMAs and the prefetch
+    // (work for LATER steps: the next quad's B operands).
+    template <int HSP, bool SYNC, class PRE, class MID, class MF>
+    __device__ __forceinline__ void step(PRE&& pre, MID&& mid, MF&& mf) {
         f32x4 cur[HSP];
 #pragma unroll
         for (int t = 0; t < HSP; ++t) cur[t] = fr[t];
@@ -137,6 +154,7 @@ struct WRing {
             if (t == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch();
+                mid();
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -162,24 +180,32 @@ struct WRing {
     }
 };
 
-// One part of a layer: NQ quads of 4 k-steps over OT out tiles, then PAD padding pieces. bsel(q, e) yields the B operand
-// of k-step 4q+e; pre(q) runs before quad q (the lazy ReLU of the previous layer's output, in place on its 4 registers).
-template <int NT, int OT, int NQ, int PAD, int NIN, class Pre, class BSel>
-__device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Pre pre, BSel bsel) {
+// One part of a layer: NQ quads of 4 k-steps over OT out tiles, then PAD padding pieces.
+//   bprep(q, b): the 4 B operands of quad q (k-steps 4q..4q+3) into b[] - for an activation array that is the lazy ReLU
+//                of 4 accumulator registers. Prepared ONE QUAD AHEAD, behind the first MFMAs of the previous quad's last
+//                step: an accumulator register reaches the VALU only through v_accvgpr_read, which goes through the
+//                matrix pipe (~10 cycles each even when nothing waits for it, tools/clockprobe/mfma_patterns.hip); read
+//                right in front of the MFMA that needs it, it cost 24 (70.0 instead of 66.5 cycles per MFMA).
+//   hook(q):     side work at the start of quad q (bias tiles of the next layer into dead registers).
+template <int NT, int OT, int NQ, int PAD, int NIN, class Hook, class BPrep>
+__device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook hook, BPrep bprep) {
     using C = LdsCfg<NT>;
     constexpr int HSP = OT >= 4 ? 4 : OT, SPQ = OT / HSP;
     static_assert((NQ * OT + PAD) % C::GP == 0, "a part is a whole number of ring groups");
+    float bq[NQ + 1][4];                                              // per-quad operands: plain registers after unrolling
+    bprep(0, bq[0]);                                                  // (the first quad's cannot be early: its source is the layer before)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
         for (int sp = 0; sp < SPQ; ++sp) {
             const int done = (q * SPQ + sp + 1) * HSP;
             auto mf = [&](int t, int e, float a) {
-                acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsel(q, e), acc[sp * HSP + t], 0, 0, 0);
+                acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[q][e], acc[sp * HSP + t], 0, 0, 0);
             };
-            auto pr = [&]() { if (sp == 0) pre(q); };
-            if (done % C::GP == 0) st.template step<HSP, true>(pr, mf);
-            else st.template step<HSP, false>(pr, mf);
+            auto pr = [&]() { if (sp == 0) hook(q); };
+            auto mid = [&]() { if (sp == SPQ - 1 && q + 1 < NQ) bprep(q + 1, bq[q + 1]); };
+            if (done % C::GP == 0) st.template step<HSP, true>(pr, mid, mf);
+            else st.template step<HSP, false>(pr, mid, mf);
         }
     }
 #pragma unroll
@@ -209,7 +235,12 @@ __device__ __forceinline__ float lds_head(const f32x16 (&x)[NIN], const float* w
         for (int r4 = 0; r4 < 4; ++r4) {
             const f32x4 wv = lds_read4(w + (t * 2 + h) * 16 + 4 * r4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s = fmaf(wv[e], relu_bits(x[t][4 * r4 + e]), s);
+            for (int e = 0; e < 4; ++e) {
+                float v = x[t][4 * r4 + e];
+                asm("" : "+v"(v));     // opaque copy: otherwise hipcc shares these ReLUs with the next layer's operand
+                                       // preparation and keeps all 128 results alive in between (spills)
+                s = fmaf(wv[e], relu_bits(v), s);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
     const int h = lane >> 5, j = lane & 31;
     const MlpLayout& L = a.lay;
     float* const cst = smem;
-    float* const park = smem + C::kConstMax + wave * (64 * 4 * kDirQuads) + lane * 4;
+    float* const park = smem + C::kConstMax + wave * (64 * 4 * C::kParkQuads) + lane * 4;
     float* const ring0 = smem + C::kConstMax + C::kParkFloats;
     {   // constant area: biases (one piece per layer), alpha head, rgb head
         const int n = (int)(L.total - L.b_off[0]);
@@ -272,15 +303,26 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
 
         float emb[4 * kEmbQuads], demb[4 * kDirQuads];
         encode_sample(a, s, h, emb, demb);
-        auto b_emb = [&](int q, int e) { return emb[4 * q + e]; };
-        // the view-direction operands are needed once, 9 layers from here: parked in LDS meanwhile (kept in registers
-        // they were spilled to scratch, and a scratch reload drains the LDS-DMA queue: vmcnt retires in order)
+        // The encoding operands are needed at layer 0 (now), at the skip layer (points) and at the views layer (directions),
+        // 5 and 9 layers from here. Kept in registers they were spilled to scratch, and a scratch reload drains the
+        // LDS-DMA queue (vmcnt retires in order): parked in LDS instead, one conflict-free 16-byte access per quad.
+#pragma unroll
+        for (int k = 0; k < kEmbQuads; ++k)
+            *reinterpret_cast<f32x4*>(park + k * 256) = (f32x4){emb[4 * k], emb[4 * k + 1], emb[4 * k + 2], emb[4 * k + 3]};
 #pragma unroll
         for (int k = 0; k < kDirQuads; ++k)
-            *reinterpret_cast<f32x4*>(park + k * 256) = (f32x4){demb[4 * k], demb[4 * k + 1], demb[4 * k + 2], demb[4 * k + 3]};
-
+            *reinterpret_cast<f32x4*>(park + (kEmbQuads + k) * 256) = (f32x4){demb[4 * k], demb[4 * k + 1], demb[4 * k + 2], demb[4 * k + 3]};
+        auto b_park = [&](int q, float (&b)[4]) {                                         // quad q of the parked operands
+            const f32x4 v = lds_read4(park + q * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = v[e];
+        };
         // layer 0: 63 -> W into P (its bias is already there); Q (dead) receives the bias of layer 1 meanwhile
-        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); }, b_emb);
+        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); },
+            [&](int q, float (&b)[4]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = emb[4 * q + e];
+            });
 
         // pts_linears[l] (l < D) / feature_linear (l == D): out += W_l relu(in). While it runs, `in` receives the bias of
         // layer l+1 tile by tile as its tiles die (for l == D that is the views layer: its W/2 channels use the first
@@ -289,15 +331,13 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
         auto layer = [&](f32x16 (&in)[NT], f32x16 (&out)[NT], int l, bool may_skip, bool may_be_last) {
             if (may_be_last && l == L.D) alpha = lds_head<NT>(in, c_alpha, h) + c_alpha[NT * 32];   // alpha_linear on relu(h) (RH:110)
             if (may_skip && l == L.skip + 1)                                              // h = cat([input_pts, h]) (RH:106-107)
-                lds_part<NT, NT, kEmbQuads, 0>(st, out, [](int) {}, b_emb);
+                lds_part<NT, NT, kEmbQuads, 0>(st, out, [](int) {}, b_park);
             lds_part<NT, NT, 4 * NT, 0>(st, out,
-                [&](int q) {
-                    if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1);
+                [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); },
+                [&](int q, float (&b)[4]) {                                               // lazy ReLU of quad q's 4 accumulator registers
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)                                           // lazy ReLU of quad q's 4 B registers
-                        in[q >> 2][4 * (q & 3) + e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);
-                },
-                [&](int q, int e) { return in[q >> 2][4 * (q & 3) + e]; });
+                    for (int e = 0; e < 4; ++e) b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);
+                });
             bias_tile(in, l + 1, NT - 1);
         };
 #pragma unroll 1
@@ -309,12 +349,12 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
         // the rgb head); P, its input, receives the bias of the NEXT tile's layer 0 as it dies
         lds_part<NT, OTV, 4 * NT, 0>(st, Q,
             [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(P, 0, (q >> 2) - 1); },
-            [&](int q, int e) { return P[q >> 2][4 * (q & 3) + e]; });
-        bias_tile(P, 0, NT - 1);
-        f32x4 dq[kDirQuads];
+            [&](int q, float (&b)[4]) {
 #pragma unroll
-        for (int k = 0; k < kDirQuads; ++k) dq[k] = lds_read4(park + k * 256);
-        lds_part<NT, OTV, kDirQuads, C::kStreamPad>(st, Q, [](int) {}, [&](int q, int e) { return dq[q][e]; });
+                for (int e = 0; e < 4; ++e) b[e] = P[q >> 2][4 * (q & 3) + e];
+            });
+        bias_tile(P, 0, NT - 1);
+        lds_part<NT, OTV, kDirQuads, C::kStreamPad>(st, Q, [](int) {}, [&](int q, float (&b)[4]) { b_park(kEmbQuads + q, b); });
         float rgb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)                                                       // rgb_linear: W/2 -> 3 (RH:118)

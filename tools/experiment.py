@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Timing experiments WITHOUT experiment code in the product sources: builds libnerfail_hip_exp_<name>.so from a PATCHED
+COPY of one csrc file (text substitutions listed below, applied in a temp dir; every pattern must match exactly once) plus
+the product objects. Run on the GPU with  tools/microbench_mlp.py --lib nerfail_amd/lib/libnerfail_hip_exp_<name>.so.
+Most variants compute WRONG results on purpose (they remove work to price it) - timing only. The variant libraries are
+git-ignored; delete them afterwards (they travel with every gpurun snapshot).
+
+    python tools/experiment.py <name> [<name> ...]      |  python tools/experiment.py --list
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nerfail_amd import build as B  # noqa: E402
+
+# name -> (source file, [(old, new), ...], extra compiler flags)
+EXPERIMENTS = {
+    'lds_base': ('mlp_lds.hip', [], []),
+    'lds_gpm2': ('mlp_lds.hip', [], ['-DNF_LDS_GPM=2']),
+    'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, h, emb, demb);\n',
+                                   '        for (int i_ = 0; i_ < 4 * kEmbQuads; ++i_) emb[i_] = 0.25f * (float)(lane & 3) + (float)s * 1e-9f;\n'
+                                   '        for (int i_ = 0; i_ < 4 * kDirQuads; ++i_) demb[i_] = 0.5f;\n')], []),
+    'lds_nodma': ('mlp_lds.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + piece) * kPiece),\n'
+                                   '                                         (lds_void_t*)(ring + (slot * C::GP + piece) * kPiece), 16, 0, 0);\n',
+                                   '        asm volatile("" :: "s"(piece));\n')], []),
+    'lds_nobarrier': ('mlp_lds.hip', [('        __builtin_amdgcn_s_barrier();\n        asm volatile("" ::: "memory");\n',
+                                       '        asm volatile("" ::: "memory");\n')], []),
+    # shader-clock stamps of one tile's phases -> raw[(block*4 + wave)] as 4 uint32 deltas (timing only, outputs destroyed)
+    'lds_clock': ('mlp_lds.hip', [
+        ('        const long s = sraw < a.M ? sraw : a.M - 1;\n',
+         '        const long s = sraw < a.M ? sraw : a.M - 1;\n        const unsigned long long c0_ = clock64();\n'),
+        ('        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); }, b_emb);\n',
+         '        const unsigned long long c1_ = clock64();\n'
+         '        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); }, b_emb);\n'
+         '        const unsigned long long c2_ = clock64();\n'),
+        ('        // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q\'s first tiles',
+         '        const unsigned long long c3_ = clock64();\n        // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q\'s first tiles'),
+        ('        if (h == 0 && sraw < a.M && tile_own < ntiles)\n'
+         '            reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);\n',
+         '        const unsigned long long c4_ = clock64();\n'
+         '        if (rnd == nrounds - 2 && lane == 0) {\n'
+         '            unsigned* o_ = reinterpret_cast<unsigned*>(a.raw) + (blockIdx.x * 4 + wave) * 8;\n'
+         '            o_[0] = (unsigned)(c1_ - c0_); o_[1] = (unsigned)(c2_ - c1_); o_[2] = (unsigned)(c3_ - c2_); o_[3] = (unsigned)(c4_ - c3_);\n'
+         '            o_[4] = __float_as_uint(rgb[0] + rgb[1] + rgb[2] + alpha); o_[5] = (unsigned)wall_clock64();\n'
+         '        }\n')], []),
+    'lds_nobias': ('mlp_lds.hip', [('                    if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1);\n', ''),
+                                   ('            bias_tile(in, l + 1, NT - 1);\n', '')], []),
+    'lds_norelu': ('mlp_lds.hip', [('in[q >> 2][4 * (q & 3) + e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);', ';')], []),
+    'lds_noread': ('mlp_lds.hip', [('        for (int t = 0; t < C::HS; ++t) fr[t] = lds_read4(rl + (rd + t) * kPiece);\n    }\n    __device__ __forceinline__ void start()',
+                                    '        for (int t = 0; t < C::HS; ++t) asm volatile("" : "+v"(fr[t]));\n    }\n    __device__ __forceinline__ void start()')], []),
+    # shader-clock stamp at the end of EVERY step, kept in the 64 lanes of one VGPR (v_writelane: no memory traffic);
+    # dumped at kernel end: raw[(block*4 + wave)*66 + lane] = stamp of step (idx - 64 + lane), [64] = idx
+    'lds_steps': ('mlp_lds.hip', [
+        ('    f32x4 fr[C::HS];         // fragments of the NEXT step',
+         '    unsigned st_v = 0; int st_i = 0;\n    f32x4 fr[C::HS];         // fragments of the NEXT step'),
+        ('        pre();\n        int k = 0;\n', '        pre();\n        const unsigned st_t = (unsigned)clock64();\n        int k = 0;\n'),
+        ('            if (t == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n',
+         '            if (t == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n'
+         '                st_v = ((int)(threadIdx.x & 63) == (st_i & 63)) ? st_t : st_v; ++st_i;\n'),
+        ('    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight',
+         '    { unsigned* o_ = reinterpret_cast<unsigned*>(a.raw) + (blockIdx.x * 4 + wave) * 66; o_[lane] = st.st_v; if (lane == 0) o_[64] = st.st_i; }\n'
+         '    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight')], []),
+    'lds_noheads': ('mlp_lds.hip', [('    return s + __shfl_xor(s, 32, 64);\n}\n\n// SKIP:', '    return w[h];\n}\n\n// SKIP:'),
+                                    ('        __builtin_amdgcn_sched_barrier(0);\n    }\n    return', '    }\n    return'),
+                                    ('            for (int e = 0; e < 4; ++e) s = fmaf(wv[e], relu_bits(x[t][4 * r4 + e]), s);\n',
+                                     '            if (t > 99) s += wv[0];\n')], []),
+}
+
+
+def main():
+    if '--list' in sys.argv:
+        print('\n'.join(EXPERIMENTS))
+        return
+    B.build()
+    for name in sys.argv[1:]:
+        parts = [EXPERIMENTS[n] for n in name.split('+')]             # a+b: both patch sets on the same source
+        assert len({p_[0] for p_ in parts}) == 1
+        src, patches, flags = parts[0][0], sum((p_[1] for p_ in parts), []), sum((p_[2] for p_ in parts), [])
+        text = open(os.path.join(B.CSRC, src)).read()
+        for old, new in patches:
+            assert text.count(old) == 1, 'experiment %s: pattern does not match exactly once:\n%s' % (name, old)
+            text = text.replace(old, new)
+        tmp = tempfile.mkdtemp(prefix='nf_exp_')
+        try:
+            for f in os.listdir(B.CSRC):
+                if f.endswith('.h'):
+                    shutil.copy(os.path.join(B.CSRC, f), tmp)
+            open(os.path.join(tmp, src), 'w').write(text.replace('"../../include/', '"' + B.INCLUDE + '/'))
+            for f in os.listdir(tmp):
+                if f.endswith('.h'):
+                    t = open(os.path.join(tmp, f)).read()
+                    open(os.path.join(tmp, f), 'w').write(t.replace('"../../include/', '"' + B.INCLUDE + '/'))
+            o = os.path.join(B.OBJDIR, 'exp_%s.o' % name)
+            subprocess.check_call([B.HIPCC] + B.CFLAGS + flags + ['-c', os.path.join(tmp, src), '-o', o])
+        finally:
+            shutil.rmtree(tmp)
+        objs = [os.path.join(B.OBJDIR, f[:-4] + '.o') for f in B._sources() if f != src] + [o]
+        lib = os.path.join(B.LIBDIR, 'libnerfail_hip_exp_%s.so' % name)
+        subprocess.check_call([B.HIPCC, '--offload-arch=' + B.ARCH, '-shared', '-fPIC', '-o', lib] + objs)
+        print(lib, flush=True)
+
+
+if __name__ == '__main__':
+    main()
