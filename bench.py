@@ -617,7 +617,7 @@ def main():
                                    'one view per step per GPU (BASELINE.json configs[1])',
                        'rays_per_step_per_gpu': H * W, 'chunk': H * W, 'pass': 'forward (render)',
                        'parallelism': 'view-per-rank, no collective'},
-            'roofline': {'bound': 'mfma', 'kernel': 'nerf_mlp_fwd_kernel<8>', 'achieved': achieved,
+            'roofline': {'bound': 'mfma', 'kernel': 'nerf_mlp_fwd_lds_kernel<8,1>', 'achieved': achieved,
                          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
                          'traffic': traffic, 'traffic_unit': 'HBM+IC bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                          'traffic_source': traffic_source,

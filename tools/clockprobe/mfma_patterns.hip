@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256, 1) void probe(int iters, float* out, unsigned 
     float tbn[16] = {};
     float bn[4] = {0.f, 0.f, 0.f, 0.f};
     const unsigned long long c0 = clock64();
-#pragma unroll UNR
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; it += UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
 #pragma unroll
         for (int qq = 0; qq < 32; ++qq) {        // 32 steps of 16 MFMAs (all register indices static)
             const int q = qq >> 2, kq = qq & 3;
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256, 1) void probe(int iters, float* out, unsigned 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+      }
     }
     const unsigned long long c1 = clock64();
     float s = 0.f;

@@ -33,10 +33,10 @@ EXPERIMENTS = {
     'lds_clock': ('mlp_lds.hip', [
         ('        const long s = sraw < a.M ? sraw : a.M - 1;\n',
          '        const long s = sraw < a.M ? sraw : a.M - 1;\n        const unsigned long long c0_ = clock64();\n'),
-        ('        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); }, b_emb);\n',
-         '        const unsigned long long c1_ = clock64();\n'
-         '        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); }, b_emb);\n'
-         '        const unsigned long long c2_ = clock64();\n'),
+        ('        // layer 0: 63 -> W into P (its bias is already there); Q (dead) receives the bias of layer 1 meanwhile\n',
+         '        const unsigned long long c1_ = clock64();\n'),
+        ('        // pts_linears[l] (l < D) / feature_linear (l == D): out += W_l relu(in).',
+         '        const unsigned long long c2_ = clock64();\n        // pts_linears[l] (l < D) / feature_linear (l == D): out += W_l relu(in).'),
         ('        // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q\'s first tiles',
          '        const unsigned long long c3_ = clock64();\n        // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q\'s first tiles'),
         ('        if (h == 0 && sraw < a.M && tile_own < ntiles)\n'
@@ -64,6 +64,11 @@ EXPERIMENTS = {
         ('    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight',
          '    { unsigned* o_ = reinterpret_cast<unsigned*>(a.raw) + (blockIdx.x * 4 + wave) * 66; o_[lane] = st.st_v; if (lane == 0) o_[64] = st.st_i; }\n'
          '    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight')], []),
+    'lds_emajor': ('mlp_lds.hip', [
+        ('        for (int t = 0; t < HSP; ++t) {\n#pragma unroll\n            for (int e = 0; e < 4; ++e) {\n                mf(t, e, cur[t][e]);',
+         '        for (int e = 0; e < 4; ++e) {\n#pragma unroll\n            for (int t = 0; t < HSP; ++t) {\n                mf(t, e, cur[t][e]);'),
+        ('            if (t == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n                prefetch();',
+         '            if (e == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n                prefetch();')], []),
     'lds_noheads': ('mlp_lds.hip', [('    return s + __shfl_xor(s, 32, 64);\n}\n\n// SKIP:', '    return w[h];\n}\n\n// SKIP:'),
                                     ('        __builtin_amdgcn_sched_barrier(0);\n    }\n    return', '    }\n    return'),
                                     ('            for (int e = 0; e < 4; ++e) s = fmaf(wv[e], relu_bits(x[t][4 * r4 + e]), s);\n',
