@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NERFAIL_ABI_VERSION 1
+#define NERFAIL_ABI_VERSION 2
 
 #define NERFAIL_OK 0
 #define NERFAIL_EINVAL 1   /* bad argument (null pointer, size, unsupported shape) */
@@ -117,6 +117,12 @@ int nerfail_mlp_pack(const nerfail_mlp_params* params_host, float* packed, void*
  * pts[M,3]; viewdirs[n_rays,3] with sample m using row m / samples_per_ray; raw[M,4] = rgb(3), sigma(1). */
 int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, const float* pts, const float* viewdirs,
                     int64_t M, int samples_per_ray, float* raw, void* stream);
+
+/* Which kernel serves nerfail_mlp_fwd / nerfail_mlp_fwd_embedded: 0 = automatic (default: the LDS-streaming kernel for
+ * even depths <= 8, else the register-streamed one), 1 = register-streamed (mlp.hip), 2 = LDS-streaming (mlp_lds.hip;
+ * shapes it does not cover return NERFAIL_EINVAL). Both compute the same f32 FMA chains in the same order; the switch
+ * exists for A/B timing and for the parity test of one against the other. Process-wide; returns the previous value. */
+int nerfail_mlp_fwd_select(int which);
 
 /* NeRF.forward on an already embedded batch x[M, 63+27] (RH:100-123 as a standalone call). */
 int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int skip, const float* x, int64_t M,
@@ -230,22 +236,27 @@ int nerfail_gauss_bwd(const float* weight_and_index, const float* ori_img, const
  *   row_ptr[Ns+1] int32, contrib[B*P*8] int32 (contribution id), w_sorted[B*P*8] (its weight).
  * workspace: nerfail_gauss_csr_workspace_bytes() bytes of scratch (0 = sizes unsupported). */
 size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64_t P);
+/* row_of [B*P*8] int32: the destination row of every entry of the row-sorted list (contrib / w_sorted are in that order);
+ * entries of weight 0 are sorted behind row_ptr[Ns] and never visited. */
 int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns, int64_t B, int64_t P, int32_t* row_ptr,
-                            int32_t* contrib, float* w_sorted, void* workspace, size_t workspace_bytes, void* stream);
-/* grad_spatial[Ns,4] = (accumulate ? grad_spatial : 0) + gather-reduce of the per-pixel gradient over the
- * inverted index: no atomics, fixed summation order, bitwise reproducible. pixel_grad_scratch: B*P*4 floats. */
+                            int32_t* contrib, float* w_sorted, int32_t* row_of, void* workspace, size_t workspace_bytes,
+                            void* stream);
+/* floats of scratch the two backward calls below need (per-pixel gradients + partial-row records); 0 = bad arguments */
+size_t nerfail_gauss_bwd_scratch_floats(int64_t B, int64_t P, int n_rhs);
+/* grad_spatial[Ns,4] = (accumulate ? grad_spatial : 0) + segmented reduction of w_e * (per-pixel gradient) over the
+ * row-sorted entries: no atomics, fixed summation order, bitwise reproducible. */
 int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
-                          const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns, int64_t B,
-                          int64_t P, float epsilon, float* pixel_grad_scratch, int accumulate, float* grad_spatial,
-                          void* stream);
+                          const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, const int32_t* row_of,
+                          int64_t Ns, int64_t B, int64_t P, float epsilon, float* scratch, int accumulate,
+                          float* grad_spatial, void* stream);
 
 /* The same backward for n_rhs (1..8) upstream gradients at once - the class-logit gradients of one DeepFool iteration
  * (deepfool.py:66-96 takes them one autograd.grad call at a time). grad_x_rgba: [n_rhs][B*P,4]; grad_spatial:
- * [n_rhs][Ns,4], overwritten; pixel_grad_scratch: n_rhs*B*P*4 floats. Row sums run in the same order as
- * nerfail_gauss_bwd_csr, so each right-hand side gets bitwise the result of a single call. */
+ * [n_rhs][Ns,4], overwritten. Sums run in the same order as nerfail_gauss_bwd_csr, so each right-hand side gets bitwise
+ * the result of a single call. */
 int nerfail_gauss_bwd_csr_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,
-                                const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns,
-                                int64_t B, int64_t P, float epsilon, float* pixel_grad_scratch, float* grad_spatial,
+                                const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, const int32_t* row_of,
+                                int64_t Ns, int64_t B, int64_t P, float epsilon, float* scratch, float* grad_spatial,
                                 void* stream);
 
 /* K14 - DeepFool step arithmetic over the perturbation table (deepfool.py:76-102). grads = [n_rhs][n,4] as written by

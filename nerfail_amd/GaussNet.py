@@ -14,7 +14,8 @@ from .run_nerf_helpers import _cuda
 
 class GaussCSR:
     """Inverted index of a batch of views' 8-NN maps (built once per batch tensor, reused by every backward):
-    row_ptr [Ns+1] int32, contrib [B*P*8] int32, w_sorted [B*P*8] float32 (nerfail_gauss_csr_build)."""
+    row_ptr [Ns+1] int32, contrib / w_sorted / row_of [B*P*8] (nerfail_gauss_csr_build: the entries sorted by
+    destination row, zero-weight entries dropped behind row_ptr[Ns])."""
 
     def __init__(self, wi, Ns):
         lib = _lib.load()
@@ -27,9 +28,11 @@ class GaussCSR:
         self.row_ptr = torch.empty((Ns + 1,), dtype=torch.int32, device=dev)
         self.contrib = torch.empty((B * P * 8,), dtype=torch.int32, device=dev)
         self.w_sorted = torch.empty((B * P * 8,), dtype=torch.float32, device=dev)
+        self.row_of = torch.empty((B * P * 8,), dtype=torch.int32, device=dev)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         _lib.check(lib.nerfail_gauss_csr_build(_lib.dev(wi), Ns, B, P, _lib.dev(self.row_ptr), _lib.dev(self.contrib),
-                                               _lib.dev(self.w_sorted), _lib.dev(ws), nbytes, _lib.stream()))
+                                               _lib.dev(self.w_sorted), _lib.dev(self.row_of), _lib.dev(ws), nbytes,
+                                               _lib.stream()))
         self._wi = wi          # keeps the map alive so its address cannot be recycled under the cache key
 
 
@@ -85,10 +88,11 @@ class _GaussGather(torch.autograd.Function):
         if ctx.deterministic:
             csr = csr_for(wi, n)
             gs = torch.empty((n, 4), dtype=torch.float32, device=x.device)
-            scratch = torch.empty((B * P, 4), dtype=torch.float32, device=x.device)
+            scratch = torch.empty((lib.nerfail_gauss_bwd_scratch_floats(B, P, 1),), dtype=torch.float32, device=x.device)
             _lib.check(lib.nerfail_gauss_bwd_csr(_lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr),
                                                  _lib.dev(csr.row_ptr), _lib.dev(csr.contrib), _lib.dev(csr.w_sorted),
-                                                 n, B, P, ctx.eps, _lib.dev(scratch), 0, _lib.dev(gs), _lib.stream()))
+                                                 _lib.dev(csr.row_of), n, B, P, ctx.eps, _lib.dev(scratch), 0, _lib.dev(gs),
+                                                 _lib.stream()))
         else:
             gs = torch.zeros((n, 4), dtype=torch.float32, device=x.device)
             _lib.check(lib.nerfail_gauss_bwd(_lib.dev(wi), _lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr),
@@ -128,6 +132,10 @@ class gauss_net(nn.Module):
         # (a classifier in train() mode, e.g. with dropout, is not a pure function of its input).
         self.cache_ori_cla = False
         self._ori_cla_cache = {}
+        # The cold tail hands the classifier a NCHW *view* of NHWC data (GN:121-131). MIOpen has no fp32 solver for that
+        # layout and falls back to naive_conv_* kernels (17 ms per 8-view forward of the 800x800 victim CNN, 73 % of an
+        # attack iteration). True: same values, copied to packed NCHW first (the layout torchvision models are tuned for).
+        self.classifier_input_contiguous = True
         self._eps_minmax = None      # device-side running [min, max] of x_rgb*alpha (GN:89-103), read lazily
 
     # -- resize of the cold tail: torchvision if present (as the reference), else the same bilinear op in torch
@@ -179,6 +187,9 @@ class gauss_net(nn.Module):
         cla_x_3channel = torch.where(cla_x[:, 3:4] > 0, cla_x[:, :3], torch.full_like(cla_x[:, :3], 255.))
         cla_ori_img_3channel = torch.where(cla_ori_img[:, 3:4] > 0, cla_ori_img[:, :3],
                                            torch.full_like(cla_ori_img[:, :3], 255.))
+        if self.classifier_input_contiguous:
+            cla_x_3channel = cla_x_3channel.contiguous()
+            cla_ori_img_3channel = cla_ori_img_3channel.contiguous()
         if self.model_name == "my_model":
             pass
         elif self.model_name == "vit_b_16":
@@ -232,12 +243,13 @@ class gauss_net(nn.Module):
         J = _lib.f32c(J).reshape(C, B * P, 4)
         ori = _lib.f32c(self._last_ori)
         out = torch.empty((C, n, 4), dtype=torch.float32, device=J.device)
-        scratch = torch.empty((C * B * P, 4), dtype=torch.float32, device=J.device)
+        scratch = torch.empty((_lib.load().nerfail_gauss_bwd_scratch_floats(B, P, C),), dtype=torch.float32, device=J.device)
         eps = -1.0 if self.epsilon is None else float(self.epsilon)
         x_c = _lib.f32c(x)            # bound to a name: see deepfool.py on pointers of temporaries
         _lib.check(_lib.load().nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(x_c), _lib.dev(J), C,
                                                            _lib.dev(csr.row_ptr), _lib.dev(csr.contrib), _lib.dev(csr.w_sorted),
-                                                           n, B, P, eps, _lib.dev(scratch), _lib.dev(out), _lib.stream()))
+                                                           _lib.dev(csr.row_of), n, B, P, eps, _lib.dev(scratch), _lib.dev(out),
+                                                           _lib.stream()))
         return out.reshape((C,) + tuple(spatial_rgb.shape))
 
 

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: libnerfail_hip.so binds to 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFAIL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerfail_hip.so')   # override: A/B builds (tools/ablate.py)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DEPTH = 16
 RAY_FLOATS = 11
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     'nerfail_mlp_packed_floats': (ctypes.c_size_t, [c_i, c_i, c_i]),
     'nerfail_mlp_pack': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
     'nerfail_mlp_fwd': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
+    'nerfail_mlp_fwd_select': (c_i, [c_i]),
     'nerfail_mlp_fwd_embedded': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p]),
     'nerfail_mlp_f16_image_bytes': (ctypes.c_size_t, [c_i, c_i, c_i]),
     'nerfail_mlp_pack_f16': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
@@ -74,9 +75,10 @@ SIGNATURES = {
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_csr_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i64, c_i64]),
-    'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
-    'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
-    'nerfail_gauss_bwd_csr_multi': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
+    'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    'nerfail_gauss_bwd_scratch_floats': (ctypes.c_size_t, [c_i64, c_i64, c_i]),
+    'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
+    'nerfail_gauss_bwd_csr_multi': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     'nerfail_deepfool_norms_scratch_bytes': (ctypes.c_size_t, [c_i, c_i64]),
     'nerfail_deepfool_norms': (c_i, [c_p, c_i, c_i64, c_p, ctypes.c_size_t, c_p, c_p]),
     'nerfail_deepfool_apply': (c_i, [c_p, c_i, c_i64, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),

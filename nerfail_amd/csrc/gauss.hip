@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict
         for (int k = 0; k < 8; ++k) {     // issue all 8 gathers before using any
             long j = (long)fi[k];         // .type(torch.long): truncation (GN:62)
             j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
-            rows[k] = spatial[j];
+            // a neighbour with weight 0 contributes 0 * s = 0: its row is not fetched (background pixels - 60 % of a real
+            // view - have all 8 weights at 0, GN:181)
+            rows[k] = (w[k] != 0.f) ? spatial[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

@@ -24,7 +24,13 @@ __global__ __launch_bounds__(256) void csr_keys_kernel(const float* __restrict__
     const long b = bp / P, p = bp - b * P;
     long j = (long)wi[((b * 2 + 1) * P + p) * 8 + k];
     j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
-    keys[g] = (unsigned)j;          // one list per destination row over the WHOLE batch (ids ascending inside: b, p, k)
+    // A contribution with weight 0 adds w * g = 0 to its row: it is left out of the index (key Ns sorts it behind the last
+    // row, row_ptr[Ns] ends before it). On real maps that is most of them: a background pixel's 3-D point (near plane,
+    // NC:418-423) is far from every point of the set, all 8 Gaussian weights underflow to 0 (GN:181), and its 8
+    // "neighbours" are the same few boundary points for hundreds of thousands of pixels - rows that long kept one wave
+    // busy for milliseconds after the rest of the grid had finished. (The atomic form skips w == 0 as well.)
+    const float w = wi[((b * 2 + 0) * P + p) * 8 + k];
+    keys[g] = (w == 0.f) ? (unsigned)Ns : (unsigned)j;   // one list per destination row over the WHOLE batch (ids ascending inside: b, p, k)
     vals[g] = (int)g;
 }
 
@@ -87,153 +93,167 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __r
     g_out[g] = gx;
 }
 
-// pass 2: one thread per destination row, contributions of the whole batch in ascending id order (fixed order =>
-// bitwise reproducible).
-//   * The 64 rows of a wave are one CONTIGUOUS range of the index arrays (~21 entries per row): the wave first copies
-//     that range into LDS with coalesced loads (lane i takes entries i, i+64, ...). Walking the rows straight from
-//     global memory instead makes every lane stream its own 84-byte-strided slice: ~43 cache lines per wave load, L1
-//     thrash, ~30x read amplification.
-//   * The trip count is WAVE-UNIFORM (max row length of the wave) and all loads are unconditional (clamped index,
-//     weight 0 past the row's end), so the 4x unrolled loop keeps the 16-byte gathers of 4 contributions in flight.
-// Gathers in flight per lane and loop iteration. The row walk is latency bound (16-byte gathers out of an 80 MB
-// array): 4 -> 1.74 ms per 8-view iteration, 8 -> 1.58, 16 -> 1.42, 32 (a whole typical row at once) -> 1.33.
-#ifndef NF_ROW_UNROLL
-#define NF_ROW_UNROLL 32
-#endif
-#ifndef NF_ROW_ABLATE
-#define NF_ROW_ABLATE 0     // timing experiments: 1 no gathers, 2 no output store, 3 no LDS staging (direct loads)
-#endif
-#ifndef NF_ROW_CAP
-#define NF_ROW_CAP 2048
-#endif
-constexpr int kRowCap = NF_ROW_CAP;    // index entries staged per wave (8 B each in LDS); longer ranges take the direct path
+// pass 2: grad_s[j] = sum over the entries of row j of w_e * g[pixel_e], as a SEGMENTED REDUCTION OVER ENTRIES.
+// Real maps have very uneven rows (a surface point seen at a grazing angle by a base view is the neighbour of thousands
+// of pixels of other views, most rows of background points have no entry at all): with one lane per row the longest
+// rows of a wave set its run time (1.1 ms per 8-view batch; 4.8 ms before zero-weight entries were dropped). Here every
+// lane owns ENTRIES instead: a wave takes kSegChunk consecutive entries of the row-sorted list, 64 at a time with
+// coalesced index loads and 64 x U independent 16-byte gathers in flight, multiplies, and sums runs of equal row id with
+// a wave-wide segmented scan (6 shuffle steps); a run that continues into the next 64 entries is carried in registers.
+// Rows that lie inside one chunk are written directly; a row that crosses chunk boundaries leaves one partial record per
+// chunk, combined in chunk order by gauss_seg_combine_kernel. Every order is fixed: bitwise reproducible, no atomics,
+// and the same for 1 and for C right-hand sides (the multi-RHS slices equal the single-RHS result bit for bit).
+constexpr int kSegU = 8;                       // 64-entry steps per wave
+constexpr int kSegChunk = 64 * kSegU;          // entries per wave
+constexpr int kSegNone = 0x7fffffff;           // row id of a padding lane / "no record"
 
-constexpr int kLongRow = 256;     // rows longer than this are reduced by the whole wave
+__device__ __forceinline__ float4 f4_add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// One long row, all 64 lanes: lane l takes entries l, l+64, ... (coalesced index / weight loads, 64 gathers in flight),
-// each chunk of 64 products is summed by a fixed butterfly, chunks are added in order: deterministic, and the same
-// order in the single- and the multi-RHS kernel. Every lane returns the total.
 template <int C>
-__device__ __forceinline__ void long_row(const int* __restrict__ contrib, const float* __restrict__ w_sorted,
-                                         const float4* __restrict__ g_pix, int c0, int len, int lane, float4 (&tot)[C]) {
+__global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __restrict__ n_entries, const int* __restrict__ row_of,
+                                                               const int* __restrict__ contrib, const float* __restrict__ w_sorted,
+                                                               const float4* __restrict__ g_pix, int accumulate,
+                                                               float4* __restrict__ grad_spatial, long Ns,
+                                                               int* __restrict__ rec_row, float4* __restrict__ rec_val) {
+    // UB: steps whose gathers are issued together (register budget: UB * C float4 per lane)
+    constexpr int UB = C == 1 ? 8 : (C == 2 ? 4 : (C <= 4 ? 2 : 1));
+    const int lane = threadIdx.x & 63;
+    const long wg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);         // chunk = wave
+    const long E = *n_entries;
+    const long base = wg * kSegChunk;
+    // record slots of this chunk: [4*wg] head row, [4*wg+1] tail row, [4*wg+2] tail-starts-here flag
+    if (lane == 0) { rec_row[4 * wg] = kSegNone; rec_row[4 * wg + 1] = kSegNone; rec_row[4 * wg + 2] = 0; }
+    if (base >= E) return;                                             // wave-uniform
+    const long end = base + kSegChunk < E ? base + kSegChunk : E;
+    const int prev_row = base > 0 ? row_of[base - 1] : -1;
+    const int next_row = end < E ? row_of[end] : -1;
+    const int first_row = row_of[base];
+    const bool head_partial = first_row == prev_row;                   // the chunk's first row began in an earlier chunk
+    int carry_row = kSegNone;
+    float4 carry[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) tot[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < len; k += 64) {
-        const int i = k + lane;
-        const bool ok = i < len;
-        const int ci = c0 + (ok ? i : 0);
-        const int id = contrib[ci];
-        const float w = ok ? w_sorted[ci] : 0.f;
+    for (int c = 0; c < C; ++c) carry[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto emit = [&](int row, const float4 (&v)[C], bool owner) {       // a row whose sum is complete inside this chunk
+        if (!owner) return;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float4 g = g_pix[(long)(id >> 3) * C + c];
-            float4 p = ok ? make_float4(w * g.x, w * g.y, w * g.z, w * g.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o = v[c];
+            if (accumulate) o = f4_add(grad_spatial[(long)c * Ns + row], o);
+            grad_spatial[(long)c * Ns + row] = o;
+        }
+    };
+
+#pragma unroll 1
+    for (int u0 = 0; u0 < kSegU; u0 += UB) {
+        if (base + (long)u0 * 64 >= end) break;                        // wave-uniform
+        int key[UB];
+        float w[UB];
+        float4 g[UB][C];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64);
-                p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
+        for (int u = 0; u < UB; ++u) {                                 // all loads of the batch first (clamped: unconditional)
+            const long i = base + (long)(u0 + u) * 64 + lane;
+            const bool ok = i < end;
+            const long ic = ok ? i : end - 1;
+            const int id = contrib[ic];
+            key[u] = ok ? row_of[ic] : kSegNone;
+            w[u] = ok ? w_sorted[ic] : 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id >> 3) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (base + (long)(u0 + u) * 64 >= end) break;              // wave-uniform
+            float4 v[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                v[c] = key[u] != kSegNone ? make_float4(w[u] * g[u][c].x, w[u] * g[u][c].y, w[u] * g[u][c].z, w[u] * g[u][c].w)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);   // (keeps 0 * inf of a clamped lane out)
+            // inclusive segmented scan over the 64 lanes (keys are sorted: equal keys are contiguous)
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int key_up = __shfl_up(key[u], dlt, 64);          // (every lane takes part: no shuffle under a condition)
+                const bool same = lane >= dlt && key_up == key[u];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float ax = __shfl_up(v[c].x, dlt, 64), ay = __shfl_up(v[c].y, dlt, 64);
+                    const float az = __shfl_up(v[c].z, dlt, 64), aw = __shfl_up(v[c].w, dlt, 64);
+                    if (same) { v[c].x += ax; v[c].y += ay; v[c].z += az; v[c].w += aw; }
+                }
             }
-            tot[c].x += p.x; tot[c].y += p.y; tot[c].z += p.z; tot[c].w += p.w;
+            const int key0 = __shfl(key[u], 0, 64);
+            if (key[u] == key0 && key0 == carry_row) {                 // the run carried over from the previous 64 entries
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c] = f4_add(carry[c], v[c]);
+            } else if (lane == 0 && carry_row != kSegNone && carry_row != key0) {
+                // the carried run ended exactly at the 64-entry boundary: it is complete now
+                const bool is_head = carry_row == first_row && head_partial;
+                if (is_head) {
+                    rec_row[4 * wg] = carry_row;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = carry[c];
+                } else emit(carry_row, carry, true);
+            }
+            const int key_next = __shfl_down(key[u], 1, 64);
+            const bool closed = lane != 63 && key_next != key[u] && key[u] != kSegNone;   // run ends inside these 64 entries
+            if (closed) {
+                if (key[u] == first_row && head_partial) {             // began in an earlier chunk: partial (head) record
+                    rec_row[4 * wg] = key[u];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = v[c];
+                } else emit(key[u], v, true);
+            }
+            carry_row = __shfl(key[u], 63, 64);                        // the run of the last lane stays open
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                carry[c] = make_float4(__shfl(v[c].x, 63, 64), __shfl(v[c].y, 63, 64), __shfl(v[c].z, 63, 64), __shfl(v[c].w, 63, 64));
+        }
+    }
+    if (lane == 0 && carry_row != kSegNone) {                          // the run still open at the end of the chunk
+        const bool complete = carry_row != next_row;
+        const bool is_head = carry_row == first_row && head_partial;
+        if (complete && !is_head) emit(carry_row, carry, true);
+        else if (complete) {                                           // ends here, began earlier
+            rec_row[4 * wg] = carry_row;
+#pragma unroll
+            for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = carry[c];
+        } else {                                                       // continues in the next chunk
+            rec_row[4 * wg + 1] = carry_row;
+            rec_row[4 * wg + 2] = is_head ? 0 : 1;                     // 1: the row STARTS in this chunk
+#pragma unroll
+            for (int c = 0; c < C; ++c) rec_val[(2 * wg + 1) * C + c] = carry[c];
         }
     }
 }
 
-// Copies the wave's contiguous index / weight range into LDS. 8 coalesced load pairs are issued before the first is
-// consumed (clamped addresses, so every load is unconditional): with one pair per loop iteration the ~21 iterations of
-// a wave were a chain of exposed memory round trips - most of the kernel's time.
-__device__ __forceinline__ void stage_rows(int* __restrict__ sid, float* __restrict__ sw, const int* __restrict__ contrib,
-                                           const float* __restrict__ w_sorted, int n, int lane) {
-    constexpr int U = 8;
-    for (int i0 = 0; i0 < n; i0 += 64 * U) {
-        int id[U];
-        float w[U];
+// Rows that cross chunk boundaries: the chunk where such a row starts adds up its partial records in chunk order.
+template <int C>
+__global__ __launch_bounds__(256) void gauss_seg_combine_kernel(const int* __restrict__ rec_row, const float4* __restrict__ rec_val,
+                                                                long chunks, int accumulate, float4* __restrict__ grad_spatial,
+                                                                long Ns) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= chunks) return;
+    const int row = rec_row[4 * k + 1];
+    if (row == kSegNone || rec_row[4 * k + 2] == 0) return;            // no open row here, or it did not start here
+    float4 s[C];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 64 + lane;
-            const int ic = i < n ? i : n - 1;
-            id[u] = contrib[ic];
-            w[u] = w_sorted[ic];
+    for (int c = 0; c < C; ++c) s[c] = rec_val[(2 * k + 1) * C + c];
+    for (long kk = k + 1; kk < chunks; ++kk) {
+        if (rec_row[4 * kk] == row) {                                  // the row ends in chunk kk
+#pragma unroll
+            for (int c = 0; c < C; ++c) s[c] = f4_add(s[c], rec_val[(2 * kk) * C + c]);
+            break;
         }
+        if (rec_row[4 * kk + 1] != row) break;                         // (cannot happen: a row's chunks are contiguous)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * 64 + lane;
-            if (i < n) { sid[i] = id[u]; sw[i] = w[u]; }
-        }
+        for (int c = 0; c < C; ++c) s[c] = f4_add(s[c], rec_val[(2 * kk + 1) * C + c]);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes before its reads
-}
-
-__global__ __launch_bounds__(256) void gauss_row_reduce_kernel(const int* __restrict__ row_ptr, const int* __restrict__ contrib,
-                                                               const float* __restrict__ w_sorted,
-                                                               const float4* __restrict__ g_pix, long Ns,
-                                                               int accumulate, float4* __restrict__ grad_spatial) {
-    __shared__ int s_id[4][kRowCap];
-    __shared__ float s_w[4][kRowCap];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long j0 = j - lane;                      // first row of this wave
-    if (j0 >= Ns) return;                          // whole wave out of range
-    const unsigned long long nf_t0 = (NF_ROW_ABLATE == 9) ? wall_clock64() : 0;
-    const long jc = j < Ns ? j : Ns - 1;
-    const int c0 = row_ptr[jc];
-    const int len_raw = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
-    // A row far longer than the typical ~21 entries (a point that is the neighbour of thousands of pixels) would keep
-    // its one lane - and so the whole kernel - busy long after everything else has finished: such rows are left out of
-    // the lane-per-row walk and reduced afterwards by all 64 lanes together (long_row()).
-    const bool is_long = len_raw > kLongRow;
-    const int len = is_long ? 0 : len_raw;
-    const int base = __shfl(c0, 0, 64);
-    const long jl = (j0 + 64 < Ns) ? j0 + 64 : Ns;
-    const int n = row_ptr[jl] - base;              // entries of the wave's 64 rows (wave-uniform)
-    int maxlen = len;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned long long nf_t1 = (NF_ROW_ABLATE == 9) ? wall_clock64() + (unsigned long long)(maxlen & 0) : 0;
-    const bool staged = n <= kRowCap && NF_ROW_ABLATE != 3;
-    if (staged) stage_rows(s_id[wv], s_w[wv], contrib + base, w_sorted + base, n, lane);
-    const unsigned long long nf_t2 = (NF_ROW_ABLATE == 9) ? wall_clock64() + (unsigned long long)(s_id[wv][0] & 0) : 0;
-    const int r0 = c0 - base;
-    constexpr int U = NF_ROW_UNROLL;               // gathers in flight per lane and iteration
-    for (int k = 0; k < maxlen; k += U) {
-        int id[U];
-        float w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = k + u < len;
-            const int c = ok ? r0 + k + u : 0;
-            if (staged) { id[u] = s_id[wv][c]; w[u] = s_w[wv][c]; }
-            else { id[u] = contrib[base + c]; w[u] = w_sorted[base + c]; }
-            if (!ok) w[u] = 0.f;
-        }
-        float4 g[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) g[u] = (NF_ROW_ABLATE == 1) ? make_float4(w[u], 1.f, 2.f, (float)id[u]) : g_pix[id[u] >> 3];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (k + u < len) {                     // keeps 0 * inf / NaN of a foreign row out of the sum
-                acc.x += w[u] * g[u].x; acc.y += w[u] * g[u].y; acc.z += w[u] * g[u].z; acc.w += w[u] * g[u].w;
-            }
-        }
+    for (int c = 0; c < C; ++c) {
+        float4 o = s[c];
+        if (accumulate) o = f4_add(grad_spatial[(long)c * Ns + row], o);
+        grad_spatial[(long)c * Ns + row] = o;
     }
-    for (unsigned long long lm = __ballot(is_long); lm != 0; lm &= lm - 1) {     // wave-uniform: the long rows of this wave
-        const int src = __ffsll((long long)lm) - 1;
-        float4 tot[1];
-        long_row<1>(contrib, w_sorted, g_pix, __shfl(c0, src, 64), __shfl(len_raw, src, 64), lane, tot);
-        if (lane == src) acc = tot[0];
-    }
-    if (NF_ROW_ABLATE == 9) {     // phase probe: ticks (10 ns) of header / staging / row walk, written instead of the result
-        const unsigned long long nf_t3 = wall_clock64() + (unsigned long long)(__float_as_uint(acc.x) & 0u);
-        if (j < Ns) grad_spatial[j] = make_float4((float)(nf_t1 - nf_t0), (float)(nf_t2 - nf_t1), (float)(nf_t3 - nf_t2), (float)n);
-        return;
-    }
-    if (j >= Ns || (NF_ROW_ABLATE == 2 && acc.x != 123.456f)) return;
-    if (accumulate) {
-        const float4 old = grad_spatial[j];
-        acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
-    }
-    grad_spatial[j] = acc;
 }
 
 // ---- multi-RHS form (DeepFool: the gradients of all class logits of one iteration, deepfool.py:66-96). The index
@@ -275,76 +295,6 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_multi_kernel(const float
     g_out[g] = gx;
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void gauss_row_reduce_multi_kernel(const int* __restrict__ row_ptr, const int* __restrict__ contrib,
-                                                                     const float* __restrict__ w_sorted,
-                                                                     const float4* __restrict__ g_pix, long Ns,
-                                                                     float4* __restrict__ grad_spatial) {
-    __shared__ int s_id[4][kRowCap];
-    __shared__ float s_w[4][kRowCap];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long j0 = j - lane;
-    if (j0 >= Ns) return;
-    const long jc = j < Ns ? j : Ns - 1;
-    const int c0 = row_ptr[jc];
-    const int len_raw = (j < Ns) ? row_ptr[jc + 1] - c0 : 0;
-    const bool is_long = len_raw > kLongRow;       // see gauss_row_reduce_kernel
-    const int len = is_long ? 0 : len_raw;
-    const int base = __shfl(c0, 0, 64);
-    const long jl = (j0 + 64 < Ns) ? j0 + 64 : Ns;
-    const int n = row_ptr[jl] - base;
-    int maxlen = len;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-    float4 acc[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool staged = n <= kRowCap;
-    if (staged) stage_rows(s_id[wv], s_w[wv], contrib + base, w_sorted + base, n, lane);
-    const int r0 = c0 - base;
-    constexpr int U = 4;
-    for (int k = 0; k < maxlen; k += U) {          // same contribution order per row as the single-RHS kernel => same bits
-        int id[U];
-        float w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = k + u < len;
-            const int c = ok ? r0 + k + u : 0;
-            if (staged) { id[u] = s_id[wv][c]; w[u] = s_w[wv][c]; }
-            else { id[u] = contrib[base + c]; w[u] = w_sorted[base + c]; }
-            if (!ok) w[u] = 0.f;
-        }
-        float4 g[U][C];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> 3) * C + c];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (k + u < len) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    acc[c].x += w[u] * g[u][c].x; acc[c].y += w[u] * g[u][c].y;
-                    acc[c].z += w[u] * g[u][c].z; acc[c].w += w[u] * g[u][c].w;
-                }
-            }
-        }
-    }
-    for (unsigned long long lm = __ballot(is_long); lm != 0; lm &= lm - 1) {
-        const int src = __ffsll((long long)lm) - 1;
-        float4 tot[C];
-        long_row<C>(contrib, w_sorted, g_pix, __shfl(c0, src, 64), __shfl(len_raw, src, 64), lane, tot);
-        if (lane == src) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = tot[c];
-        }
-    }
-    if (j >= Ns) return;
-#pragma unroll
-    for (int c = 0; c < C; ++c) grad_spatial[(long)c * Ns + j] = acc[c];
-}
-
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t cub_temp_bytes(long n) {
@@ -352,6 +302,29 @@ static size_t cub_temp_bytes(long n) {
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
                                        (int*)nullptr, (int)n, 0, 32, (hipStream_t) nullptr);
     return bytes;
+}
+
+static long seg_chunks(long B, long P) { return (B * P * 8 + kSegChunk - 1) / kSegChunk; }
+
+// one backward over the inverted index for C right-hand sides; g_pix [B*P][C] float4 is at the start of `scratch`
+template <int C>
+static int run_seg_reduce(const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, const int32_t* row_of, long Ns,
+                          long B, long P, float* scratch, int accumulate, float* grad_spatial, hipStream_t s) {
+    const long chunks = ((seg_chunks(B, P) + 3) / 4) * 4;             // every launched wave owns record slots
+    float4* g_pix = (float4*)scratch;
+    float4* rec_val = g_pix + (size_t)B * P * C;
+    int* rec_row = (int*)(rec_val + (size_t)2 * chunks * C);
+    if (!accumulate) {                           // rows without an entry stay 0
+        hipError_t e = hipMemsetAsync(grad_spatial, 0, (size_t)C * Ns * 16, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    }
+    gauss_seg_reduce_kernel<C><<<dim3((unsigned)(chunks / 4)), dim3(256), 0, s>>>(
+        row_ptr + Ns, row_of, contrib, w_sorted, g_pix, accumulate, (float4*)grad_spatial, Ns, rec_row, rec_val);
+    NF_LAUNCHED("gauss_seg_reduce_kernel");
+    gauss_seg_combine_kernel<C><<<dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s>>>(
+        rec_row, rec_val, chunks, accumulate, (float4*)grad_spatial, Ns);
+    NF_LAUNCHED("gauss_seg_combine_kernel");
+    return NERFAIL_OK;
 }
 
 }  // namespace nerfail
@@ -362,30 +335,36 @@ extern "C" size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64
     if (Ns <= 0 || B <= 0 || P <= 0) return 0;
     const long n = B * P * 8;
     if (n >= (1L << 31) || Ns >= (1L << 31) - 1) return 0;
-    return 3 * align256((size_t)n * 4) + align256(cub_temp_bytes(n));
+    return 2 * align256((size_t)n * 4) + align256(cub_temp_bytes(n));
+}
+
+extern "C" size_t nerfail_gauss_bwd_scratch_floats(int64_t B, int64_t P, int n_rhs) {
+    if (B <= 0 || P <= 0 || n_rhs < 1 || n_rhs > 8) return 0;
+    const size_t chunks = (size_t)(((seg_chunks(B, P) + 3) / 4) * 4);
+    return (size_t)B * P * 4 * n_rhs + chunks * 2 * 4 * n_rhs + chunks * 4;      // pixel gradients, record values, record rows
 }
 
 extern "C" int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns, int64_t B, int64_t P, int32_t* row_ptr,
-                                       int32_t* contrib, float* w_sorted, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       int32_t* contrib, float* w_sorted, int32_t* row_of, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     NF_REQUIRE(Ns > 0 && B > 0 && P > 0, "bad sizes");
     const long n = B * P * 8;
     NF_REQUIRE(n < (1L << 31) && Ns < (1L << 31) - 1, "batch too large for 32-bit CSR ids");
-    NF_REQUIRE(weight_and_index && row_ptr && contrib && w_sorted && workspace, "NULL pointer");
+    NF_REQUIRE(weight_and_index && row_ptr && contrib && w_sorted && row_of && workspace, "NULL pointer");
     const size_t need = nerfail_gauss_csr_workspace_bytes(Ns, B, P);
     NF_REQUIRE(workspace_bytes >= need, "workspace too small (nerfail_gauss_csr_workspace_bytes)");
     hipStream_t s = as_stream(stream);
     char* ws = (char*)workspace;
     const size_t seg = align256((size_t)n * 4);
     unsigned* keys_in = (unsigned*)ws;
-    unsigned* keys_out = (unsigned*)(ws + seg);
-    int* vals_in = (int*)(ws + 2 * seg);
-    void* temp = ws + 3 * seg;
-    size_t temp_bytes = workspace_bytes - 3 * seg;
+    unsigned* keys_out = (unsigned*)row_of;       // the sorted keys ARE the row of every entry (Ns = dropped, at the end)
+    int* vals_in = (int*)(ws + seg);
+    void* temp = ws + 2 * seg;
+    size_t temp_bytes = workspace_bytes - 2 * seg;
     csr_keys_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(weight_and_index, Ns, B, P, keys_in, vals_in);
     NF_LAUNCHED("csr_keys_kernel");
     int bits = 1;
-    while ((1L << bits) < Ns + 1) ++bits;         // sort only the significant key bits (stable LSD radix)
+    while ((1L << bits) < Ns + 2) ++bits;         // sort only the significant key bits (stable LSD radix); key Ns = dropped
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, contrib, (int)n, 0, bits, s);
     if (e != hipSuccess) return hip_fail(e, "hipcub::DeviceRadixSort::SortPairs");
     const long rows = Ns;
@@ -397,49 +376,41 @@ extern "C" int nerfail_gauss_csr_build(const float* weight_and_index, int64_t Ns
 }
 
 extern "C" int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
-                                     const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns,
-                                     int64_t B, int64_t P, float epsilon, float* pixel_grad_scratch, int accumulate,
-                                     float* grad_spatial, void* stream) {
+                                     const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted,
+                                     const int32_t* row_of, int64_t Ns, int64_t B, int64_t P, float epsilon, float* scratch,
+                                     int accumulate, float* grad_spatial, void* stream) {
     NF_REQUIRE(Ns > 0 && B > 0 && P > 0, "bad sizes");
-    NF_REQUIRE(ori_img && x && row_ptr && contrib && w_sorted && pixel_grad_scratch && grad_spatial, "NULL pointer");
+    NF_REQUIRE(ori_img && x && row_ptr && contrib && w_sorted && row_of && scratch && grad_spatial, "NULL pointer");
     hipStream_t s = as_stream(stream);
     const long n = B * P;
     gauss_pixel_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
         (const float4*)ori_img, (const float4*)x, (const float4*)grad_x, (const float4*)grad_x_rgba, n, epsilon,
-        (float4*)pixel_grad_scratch);
+        (float4*)scratch);
     NF_LAUNCHED("gauss_pixel_grad_kernel");
-    gauss_row_reduce_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(
-        row_ptr, contrib, w_sorted, (const float4*)pixel_grad_scratch, Ns, accumulate, (float4*)grad_spatial);
-    NF_LAUNCHED("gauss_row_reduce_kernel");
-    return NERFAIL_OK;
+    return run_seg_reduce<1>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, accumulate, grad_spatial, s);
 }
 
 extern "C" int nerfail_gauss_bwd_csr_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,
-                                           const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, int64_t Ns,
-                                           int64_t B, int64_t P, float epsilon, float* pixel_grad_scratch,
-                                           float* grad_spatial, void* stream) {
+                                           const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted,
+                                           const int32_t* row_of, int64_t Ns, int64_t B, int64_t P, float epsilon,
+                                           float* scratch, float* grad_spatial, void* stream) {
     NF_REQUIRE(Ns > 0 && B > 0 && P > 0, "bad sizes");
     NF_REQUIRE(n_rhs >= 1 && n_rhs <= 8, "n_rhs must be in 1..8");
-    NF_REQUIRE(ori_img && x && grad_x_rgba && row_ptr && contrib && w_sorted && pixel_grad_scratch && grad_spatial, "NULL pointer");
+    NF_REQUIRE(ori_img && x && grad_x_rgba && row_ptr && contrib && w_sorted && row_of && scratch && grad_spatial, "NULL pointer");
     hipStream_t s = as_stream(stream);
     const long n = B * P;
     const long total = n * n_rhs;
     gauss_pixel_grad_multi_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x_rgba, n, n_rhs, epsilon, (float4*)pixel_grad_scratch);
+        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x_rgba, n, n_rhs, epsilon, (float4*)scratch);
     NF_LAUNCHED("gauss_pixel_grad_multi_kernel");
-    const dim3 grid((unsigned)((Ns + 255) / 256)), block(256);
-#define NF_ROWS(C) gauss_row_reduce_multi_kernel<C><<<grid, block, 0, s>>>(row_ptr, contrib, w_sorted, (const float4*)pixel_grad_scratch, Ns, (float4*)grad_spatial)
     switch (n_rhs) {
-        case 1: NF_ROWS(1); break;
-        case 2: NF_ROWS(2); break;
-        case 3: NF_ROWS(3); break;
-        case 4: NF_ROWS(4); break;
-        case 5: NF_ROWS(5); break;
-        case 6: NF_ROWS(6); break;
-        case 7: NF_ROWS(7); break;
-        default: NF_ROWS(8); break;
+        case 1: return run_seg_reduce<1>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
+        case 2: return run_seg_reduce<2>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
+        case 3: return run_seg_reduce<3>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
+        case 4: return run_seg_reduce<4>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
+        case 5: return run_seg_reduce<5>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
+        case 6: return run_seg_reduce<6>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
+        case 7: return run_seg_reduce<7>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
+        default: return run_seg_reduce<8>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, 0, grad_spatial, s);
     }
-#undef NF_ROWS
-    NF_LAUNCHED("gauss_row_reduce_multi_kernel");
-    return NERFAIL_OK;
 }

@@ -295,11 +295,12 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
 }
 
 // Inference goes to the LDS-streaming kernel (mlp_lds.hip) when it covers the shape (even depth <= 8); the training
-// forward (activations saved) and the other shapes run the register-streamed kernel below. NERFAIL_FWD_KERNEL=reg
-// forces the latter (A/B timing, parity tests of both).
+// forward (activations saved) and the other shapes run the register-streamed kernel below. nerfail_mlp_fwd_select /
+// NERFAIL_FWD_KERNEL=reg|lds force one of them (A/B timing, parity test of one against the other).
+static int g_fwd_select = [] { const char* e = getenv("NERFAIL_FWD_KERNEL"); return e ? (e[0] == 'r' ? 1 : (e[0] == 'l' ? 2 : 0)) : 0; }();
 static bool use_lds_kernel(const MlpArgs& a) {
-    static const int forced = [] { const char* e = getenv("NERFAIL_FWD_KERNEL"); return e ? (e[0] == 'r' ? 1 : 2) : 0; }();
-    if (forced == 1 || a.acts != nullptr) return false;
+    if (g_fwd_select == 1 || a.acts != nullptr) return false;
+    if (g_fwd_select == 2) return true;
     return !(a.lay.D & 1) && a.lay.D <= 8;
 }
 
@@ -328,6 +329,12 @@ static int launch_mlp(const MlpArgs& a, int W, hipStream_t s) {
 }  // namespace nerfail
 
 using namespace nerfail;
+
+extern "C" int nerfail_mlp_fwd_select(int which) {
+    const int prev = g_fwd_select;
+    if (which >= 0 && which <= 2) g_fwd_select = which;
+    return prev;
+}
 
 extern "C" size_t nerfail_mlp_packed_floats(int D, int W, int skip) {
     MlpLayout L;

@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu():
     # per 32-sample tile: E0 E1 V + 8 layers and feature x 8 slots + 4 hv slots + 3 slots of ReLU bit masks
     assert lib.nerfail_mlp_train_acts_floats(8, 256, 64) == 2 * (3 + 9 * 8 + 4 + 3) * 1024
     # multi-RHS gauss backward and the DeepFool step kernels: sizes and NULL pointers are rejected before any launch
-    assert lib.nerfail_gauss_bwd_csr_multi(None, None, None, 8, None, None, None, 10, 1, 10, -1.0, None, None, None) == 1
+    assert lib.nerfail_gauss_bwd_csr_multi(None, None, None, 8, None, None, None, None, 10, 1, 10, -1.0, None, None, None) == 1
     assert lib.nerfail_deepfool_norms_scratch_bytes(8, 1000) == ((1000 + 2047) // 2048) * 7 * 8
     assert lib.nerfail_deepfool_norms_scratch_bytes(1, 1000) == 0 and lib.nerfail_deepfool_norms_scratch_bytes(9, 1000) == 0
     assert lib.nerfail_deepfool_norms(None, 8, 1000, None, 0, None, None) == 1
@@ -63,7 +63,8 @@ def test_argument_validation_without_gpu():
     assert lib.nerfail_mlp_train_acts_floats(8, 100, 64) == 0
     assert lib.nerfail_knn8_grid_workspace_bytes(7) == 0 and lib.nerfail_knn8_grid_workspace_bytes(1 << 24) == 0
     assert lib.nerfail_knn8_grid_workspace_bytes(1920000) > 1920000 * 32
-    assert lib.nerfail_gauss_csr_workspace_bytes(1920000, 8, 640000) >= 3 * 4 * 8 * 640000 * 8
+    assert lib.nerfail_gauss_csr_workspace_bytes(1920000, 8, 640000) >= 2 * 4 * 8 * 640000 * 8
+    assert lib.nerfail_gauss_bwd_scratch_floats(8, 640000, 1) >= 8 * 640000 * 4 and lib.nerfail_gauss_bwd_scratch_floats(8, 640000, 9) == 0
     assert lib.nerfail_gauss_csr_workspace_bytes(10, 1 << 20, 1 << 20) == 0                 # ids would overflow 32 bits
     assert lib.nerfail_knn8_grid(None, 4, None, 100, None, None, None, None, 0, None) == 1
     assert lib.nerfail_composite_bwd(None, None, None, None, 3, 1, 1, None, None, None, None, None, None, None) == 1

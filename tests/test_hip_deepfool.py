@@ -63,15 +63,15 @@ def test_multi_rhs_backward_is_bitwise_the_single_backward(eps):
     for C in (1, 3, 8):
         J = T(rng.normal(size=(C, B * P, 4)).astype(np.float32))
         out = torch.empty((C, n, 4), device=dev())
-        scratch = torch.empty((C * B * P, 4), device=dev())
+        scratch = torch.empty((lib.nerfail_gauss_bwd_scratch_floats(B, P, C),), device=dev())
         _lib.check(lib.nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(x.detach()), _lib.dev(J), C, _lib.dev(csr.row_ptr),
-                                                   _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), n, B, P,
+                                                   _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), _lib.dev(csr.row_of), n, B, P,
                                                    -1.0 if eps is None else eps, _lib.dev(scratch), _lib.dev(out), _lib.stream()))
         for c in range(C):
             ref = torch.autograd.grad(x_rgba, st, grad_outputs=J[c].reshape(x_rgba.shape), retain_graph=True)[0]
             assert torch.equal(out[c].reshape(ref.shape), ref), (C, c)
     assert lib.nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(x.detach()), _lib.dev(J), 9, _lib.dev(csr.row_ptr),
-                                           _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), n, B, P, -1.0, _lib.dev(scratch),
+                                           _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), _lib.dev(csr.row_of), n, B, P, -1.0, _lib.dev(scratch),
                                            _lib.dev(out), _lib.stream()) != 0
 
 

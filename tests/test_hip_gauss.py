@@ -180,12 +180,12 @@ def test_backward_with_very_long_rows():
     csr = csr_for(wi, n)
     J = T(rs.normal(size=(3, B * Pp, 4)).astype(np.float32))
     out = torch.empty((3, n, 4), device=dev())
-    scratch = torch.empty((3 * B * Pp, 4), device=dev())
+    scratch = torch.empty((lib.nerfail_gauss_bwd_scratch_floats(B, Pp, 3),), device=dev())
     st = T(s).requires_grad_(True)
     x, xr = gauss_gather(st, wi, oriT, 32.0, None, True)
     xs = x.detach()
     _lib.check(lib.nerfail_gauss_bwd_csr_multi(_lib.dev(oriT), _lib.dev(xs), _lib.dev(J), 3, _lib.dev(csr.row_ptr),
-                                               _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), n, B, Pp, 32.0,
+                                               _lib.dev(csr.contrib), _lib.dev(csr.w_sorted), _lib.dev(csr.row_of), n, B, Pp, 32.0,
                                                _lib.dev(scratch), _lib.dev(out), _lib.stream()))
     for c in range(3):
         single = torch.autograd.grad(xr, st, grad_outputs=J[c].reshape(xr.shape), retain_graph=True)[0]

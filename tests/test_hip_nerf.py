@@ -273,3 +273,27 @@ def test_render_options_match_reference(golden):
     assert tuple(out[0].shape) == (4, 3)
     for v, gk in ((out[0], 'c_rays_rgb'), (out[1], 'c_rays_disp'), (out[2], 'c_rays_acc'), (out[3]['rgb0'], 'c_rays_rgb0')):
         assert rel_err(N(v), g[gk]) < 1e-4, gk
+
+
+def test_lds_streaming_kernel_equals_register_streamed_kernel():
+    """The two exact-f32 forward kernels (mlp_lds.hip: weights through an LDS ring; mlp.hip: weights through registers)
+    run the same FMA chains in the same order: their outputs must agree BITWISE, on a size that spans several rounds of
+    the persistent grid, ragged tile, both network shapes, fused encoding and embedded input."""
+    from nerfail_amd import _lib
+    from nerfail_amd.run_nerf import _mlp_points
+    lib = _lib.load()
+    rs = np.random.RandomState(3)
+    try:
+        for (D, W, seed, R, Ns) in ((8, 256, 10, 2731, 64), (4, 64, 11, 517, 192)):
+            _, net = hip_nerf(D, W, seed)
+            pts = T(rs.uniform(-3, 3, size=(R, Ns, 3)).astype(np.float32))
+            vd = rs.normal(size=(R, 3)).astype(np.float32)
+            vd = T(vd / np.linalg.norm(vd, axis=1, keepdims=True))
+            out = {}
+            for which in (1, 2):
+                lib.nerfail_mlp_fwd_select(which)
+                out[which] = _mlp_points(net, pts, vd)
+            assert torch.equal(out[1].view(torch.int32), out[2].view(torch.int32)), (D, W)
+            assert float(out[1].abs().max()) > 0
+    finally:
+        lib.nerfail_mlp_fwd_select(0)
