@@ -54,41 +54,37 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
     else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-#ifndef NF_GAUSS_NT
-#define NF_GAUSS_NT 0
-#endif
-typedef float nf_f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load4(const float4* p) {
-    const nf_f4v v = __builtin_nontemporal_load(reinterpret_cast<const nf_f4v*>(p));
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
-    const nf_f4v t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<nf_f4v*>(p));
-}
 __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict__ spatial, long Ns,
                                                         const float* __restrict__ wi, const float4* __restrict__ ori,
                                                         long B, long P, float epsilon, float4* __restrict__ x_out,
                                                         float4* __restrict__ x_rgba, float* __restrict__ eps_minmax) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 picks the XCD, each with its own L2). Neighbouring
+    // pixels gather neighbouring rows of the table, so every XCD gets ONE contiguous eighth of the pixel range instead of
+    // every eighth workgroup: a row fetched into an L2 serves the whole neighbourhood from there.
+    const long per = gridDim.x >> 3;                                           // (the grid is a multiple of 8 workgroups)
+    const long vb = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);          // virtual block: [xcd][position in its eighth]
+    const long g = vb * blockDim.x + threadIdx.x;
     float emin = 0.f, emax = 0.f;   // the running values start at 0 (GN:27-28), so 0 is neutral
     if (g < B * P) {
         const long b = g / P, p = g - b * P;
         const float4* w4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 0) * P + p) * 8);
         const float4* i4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 1) * P + p) * 8);
-        // streamed once per pass: non-temporal, so the maps do not evict the perturbation rows the gathers want in cache
-        const float4 wa = NF_GAUSS_NT ? nt_load4(w4) : w4[0], wb = NF_GAUSS_NT ? nt_load4(w4 + 1) : w4[1];
-        const float4 ia = NF_GAUSS_NT ? nt_load4(i4) : i4[0], ib = NF_GAUSS_NT ? nt_load4(i4 + 1) : i4[1];
+        const float4 wa = w4[0], wb = w4[1];
         const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-        const float fi[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+        // a background pixel (60 % of a real view): all 8 weights are 0 (GN:181) - neither its indices nor any row is read
+        const bool any = (wa.x != 0.f) | (wa.y != 0.f) | (wa.z != 0.f) | (wa.w != 0.f) | (wb.x != 0.f) | (wb.y != 0.f) | (wb.z != 0.f) | (wb.w != 0.f);
         float4 rows[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {     // issue all 8 gathers before using any
-            long j = (long)fi[k];         // .type(torch.long): truncation (GN:62)
-            j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
-            // a neighbour with weight 0 contributes 0 * s = 0: its row is not fetched (background pixels - 60 % of a real
-            // view - have all 8 weights at 0, GN:181)
-            rows[k] = (w[k] != 0.f) ? spatial[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 8; ++k) rows[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any) {
+            const float4 ia = i4[0], ib = i4[1];
+            const float fi[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {     // issue all 8 gathers before using any
+                long j = (long)fi[k];         // .type(torch.long): truncation (GN:62)
+                j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
+                if (w[k] != 0.f) rows[k] = spatial[j];     // a neighbour with weight 0 contributes 0 * s = 0: not fetched
+            }
         }
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -99,7 +95,7 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict
             x.w = __fadd_rn(x.w, __fmul_rn(rows[k].w, w[k]));
         }
         const float alpha = __fdiv_rn(x.w, 255.0f);
-        const float4 o = NF_GAUSS_NT ? nt_load4(ori + g) : ori[g];
+        const float4 o = ori[g];
         float dlt[3] = {__fmul_rn(x.x, alpha), __fmul_rn(x.y, alpha), __fmul_rn(x.z, alpha)};
         if (alpha > 0.f) {                // GN:89-103 bookkeeping uses where(alpha>0, x, 0) * alpha
 #pragma unroll
@@ -115,8 +111,8 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict
             rgb[c] = fminf(fmaxf(v, 0.f), 255.f);
         }
         const float4 xr = make_float4(rgb[0], rgb[1], rgb[2], fminf(fmaxf(o.w, 0.f), 255.f));
-        if (NF_GAUSS_NT) { nt_store4(x_out + g, x); nt_store4(x_rgba + g, xr); }
-        else { x_out[g] = x; x_rgba[g] = xr; }
+        x_out[g] = x;
+        x_rgba[g] = xr;
     }
     if (eps_minmax != nullptr) {
         emin = wave_min(emin);
@@ -225,7 +221,7 @@ extern "C" int nerfail_gauss_fwd(const float* spatial, int64_t Ns, const float* 
     if (B * P == 0) return NERFAIL_OK;
     NF_REQUIRE(spatial != nullptr && weight_and_index != nullptr && ori_img != nullptr, "NULL input pointer");
     NF_REQUIRE(x != nullptr && x_rgba != nullptr, "NULL output pointer");
-    gauss_fwd_kernel<<<dim3((unsigned)((B * P + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+    gauss_fwd_kernel<<<dim3((unsigned)(((B * P + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, as_stream(stream)>>>(
         (const float4*)spatial, Ns, weight_and_index, (const float4*)ori_img, B, P, epsilon, (float4*)x, (float4*)x_rgba,
         eps_minmax);
     NF_LAUNCHED("gauss_fwd_kernel");

@@ -11,6 +11,13 @@
 //           bound = distance from the query to the nearest block face that still has cells behind it. The search
 //           stops once the current 8th key satisfies  d2_8 < (0.999 * bound)^2  (strict, with a safety factor far
 //           above float32 rounding), so no unvisited point can enter the result or tie with it.
+// Far queries. A rendered view is ~60 % background: those pixels' "3-D points" are near-plane points (NC:418-423: argmax of
+// all-zero weights = sample 0) one to two scene units from every point of the set. On the fine grid alone (cell ~0.04)
+// such a query walks ~30 shells of ~8 R^2 cell-range lookups before its 8th distance lies inside the visited block: 60 ms
+// per view instead of 1.3. A query that has not finished after kShellCap fine shells therefore starts again on a COARSE
+// view of the same grid (4x4x4 fine cells per coarse cell, one point count each): it walks coarse shells, skips empty
+// coarse cells (one load) and coarse cells whose box is farther than the current 8th distance (arithmetic only), and
+// scans the 16 x-rows of the others. Same keys, same stopping rule (now on the coarse block): the same bits.
 // Points are image pixels' surface points: on a G ~ 124 grid shell 1 (27 cells, ~10 occupied, ~40 points each)
 // normally finishes the query, ~1000x less work than the 1.92 M-point brute-force scan.
 #include "common.h"
@@ -103,6 +110,24 @@ __global__ __launch_bounds__(256) void cell_start_kernel(const unsigned* __restr
     cell_start[c] = (int)lo;
 }
 
+constexpr int kCoarse = 4;            // fine cells per coarse cell and axis
+constexpr int kShellCap = 3;          // fine shells (beyond the query's own cell) before the coarse search takes over
+
+// points per coarse cell = sum over its 16 x-rows of 4 consecutive fine cells
+__global__ __launch_bounds__(256) void coarse_count_kernel(const int* __restrict__ cell_start, int G, int Gc, int* __restrict__ cnt) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (long)Gc * Gc * Gc) return;
+    const int X = (int)(c % Gc), Y = (int)((c / Gc) % Gc), Z = (int)(c / ((long)Gc * Gc));
+    const int x0 = X * kCoarse, x1 = min(x0 + kCoarse, G);
+    int n = 0;
+    for (int z = Z * kCoarse; z < min(Z * kCoarse + kCoarse, G); ++z)
+        for (int y = Y * kCoarse; y < min(Y * kCoarse + kCoarse, G); ++y) {
+            const long row = ((long)z * G + y) * G;
+            n += cell_start[row + x1] - cell_start[row + x0];
+        }
+    cnt[c] = n;
+}
+
 struct Top8L {
     float d[8];
     int i[8];
@@ -149,7 +174,7 @@ __device__ __forceinline__ void scan_points(const float4* __restrict__ sorted, i
 
 __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict__ queries, long nq, const Grid* __restrict__ gp,
                                                         const float4* __restrict__ sorted, const int* __restrict__ cell_start,
-                                                        float* __restrict__ dist, float* __restrict__ idx_f,
+                                                        const int* __restrict__ coarse_cnt, float* __restrict__ dist, float* __restrict__ idx_f,
                                                         int* __restrict__ idx_i) {
     const long qi = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
@@ -161,7 +186,8 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
 
-    for (int R = 0; R < G; ++R) {
+    bool done = false;
+    for (int R = 0; R < G && R <= kShellCap; ++R) {
         const int z0 = max(cz - R, 0), z1 = min(cz + R, G - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, G - 1);
         const int x0 = max(cx - R, 0), x1 = min(cx + R, G - 1);
@@ -192,10 +218,75 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
         if (cy + R < G - 1) bound = fminf(bound, (g.oy + (float)(cy + R + 1) * g.cs) - qy);
         if (cz - R > 0) bound = fminf(bound, qz - (g.oz + (float)(cz - R) * g.cs));
         if (cz + R < G - 1) bound = fminf(bound, (g.oz + (float)(cz + R + 1) * g.cs) - qz);
-        if (bound == INFINITY) break;                       // the block covers the whole grid
+        if (bound == INFINITY) { done = true; break; }      // the block covers the whole grid
         if (bound > 0.f) {
             const float sb = 0.999f * bound;
-            if (top.d[7] < sb * sb) break;                  // strict: nothing unvisited can enter or tie
+            if (top.d[7] < sb * sb) { done = true; break; } // strict: nothing unvisited can enter or tie
+        }
+    }
+    if (!done) {
+        // ---- far query: coarse shells with empty-cell and box-distance pruning (a fresh top-8: no duplicates)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
+        const int Gc = (G + kCoarse - 1) / kCoarse;
+        const float ccs = g.cs * (float)kCoarse;
+        const int CX = cx / kCoarse, CY = cy / kCoarse, CZ = cz / kCoarse;
+        for (int R = 0; R < Gc; ++R) {
+            const int Z0 = max(CZ - R, 0), Z1 = min(CZ + R, Gc - 1);
+            const int Y0 = max(CY - R, 0), Y1 = min(CY + R, Gc - 1);
+            const int X0 = max(CX - R, 0), X1 = min(CX + R, Gc - 1);
+            for (int Z = Z0; Z <= Z1; ++Z) {
+                const bool zface = (Z == CZ - R) || (Z == CZ + R);
+                for (int Y = Y0; Y <= Y1; ++Y) {
+                    const bool yface = zface || (Y == CY - R) || (Y == CY + R);
+                    const int step = yface ? 1 : max(X1 - X0, 1);        // off the faces only the two end cells belong to the shell
+                    for (int X = X0; X <= X1; X += step) {
+                        if (!yface && X != CX - R && X != CX + R) continue;
+                        if (coarse_cnt[((long)Z * Gc + Y) * Gc + X] == 0) continue;
+                        // squared distance from the query to the coarse cell's box: a lower bound for every point inside
+                        const float bx0 = g.ox + (float)X * ccs, by0 = g.oy + (float)Y * ccs, bz0 = g.oz + (float)Z * ccs;
+                        const float ddx = fmaxf(fmaxf(bx0 - qx, qx - (bx0 + ccs)), 0.f);
+                        const float ddy = fmaxf(fmaxf(by0 - qy, qy - (by0 + ccs)), 0.f);
+                        const float ddz = fmaxf(fmaxf(bz0 - qz, qz - (bz0 + ccs)), 0.f);
+                        const float md = 0.999f * sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                        if (top.d[7] < md * md) continue;                // strict, with the same safety factor as the stopping rule
+                        // inside: the same box test per fine cell (a dense surface seen from afar has its 8th distance
+                        // within a cell diagonal of the first: most of a coarse cell's points cannot enter any more)
+                        const int fx0 = X * kCoarse, fx1 = min(fx0 + kCoarse, G);
+                        for (int z = Z * kCoarse; z < min(Z * kCoarse + kCoarse, G); ++z) {
+                            const float cz0 = g.oz + (float)z * g.cs;
+                            const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
+                            for (int y = Y * kCoarse; y < min(Y * kCoarse + kCoarse, G); ++y) {
+                                const float cy0 = g.oy + (float)y * g.cs;
+                                const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
+                                const float eyz = ey * ey + ez * ez;
+                                const long row = ((long)z * G + y) * G;
+                                int b = cell_start[row + fx0];
+                                for (int x = fx0; x < fx1; ++x) {
+                                    const int e = cell_start[row + x + 1];
+                                    const float cx0 = g.ox + (float)x * g.cs;
+                                    const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
+                                    const float m = 0.999f * sqrtf(ex * ex + eyz);
+                                    if (e > b && !(top.d[7] < m * m)) scan_points(sorted, b, e, qx, qy, qz, top);
+                                    b = e;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            float bound = INFINITY;
+            if (CX - R > 0) bound = fminf(bound, qx - (g.ox + (float)(CX - R) * ccs));
+            if (CX + R < Gc - 1) bound = fminf(bound, (g.ox + (float)(CX + R + 1) * ccs) - qx);
+            if (CY - R > 0) bound = fminf(bound, qy - (g.oy + (float)(CY - R) * ccs));
+            if (CY + R < Gc - 1) bound = fminf(bound, (g.oy + (float)(CY + R + 1) * ccs) - qy);
+            if (CZ - R > 0) bound = fminf(bound, qz - (g.oz + (float)(CZ - R) * ccs));
+            if (CZ + R < Gc - 1) bound = fminf(bound, (g.oz + (float)(CZ + R + 1) * ccs) - qz);
+            if (bound == INFINITY) break;
+            if (bound > 0.f) {
+                const float sb = 0.999f * bound;
+                if (top.d[7] < sb * sb) break;
+            }
         }
     }
 #pragma unroll
@@ -215,6 +306,8 @@ static int grid_dim_for(long n) {
     return G;
 }
 
+static size_t coarse_cells(int G) { const size_t Gc = (size_t)(G + kCoarse - 1) / kCoarse; return Gc * Gc * Gc; }
+
 static size_t knn_cub_temp(long n) {
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
@@ -231,7 +324,8 @@ extern "C" size_t nerfail_knn8_grid_workspace_bytes(int64_t n_points) {
     const int G = grid_dim_for(n_points);
     const size_t ncells = (size_t)G * G * G;
     return al256(256) /* bbox + Grid */ + 4 * al256((size_t)n_points * 4) /* keys in/out, vals in/out */ +
-           al256((size_t)n_points * 16) /* sorted float4 */ + al256((ncells + 1) * 4) + al256(knn_cub_temp(n_points));
+           al256((size_t)n_points * 16) /* sorted float4 */ + al256((ncells + 1) * 4) + al256(coarse_cells(G) * 4) +
+           al256(knn_cub_temp(n_points));
 }
 
 extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* points, int64_t n_points, float* dist,
@@ -257,6 +351,7 @@ extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const 
     ws += 4 * seg;
     float4* sorted = (float4*)ws; ws += al256((size_t)n * 16);
     int* cell_start = (int*)ws; ws += al256((size_t)(ncells + 1) * 4);
+    int* coarse_cnt = (int*)ws; ws += al256(coarse_cells(G) * 4);
     void* temp = ws;
     size_t temp_bytes = knn_cub_temp(n);
 
@@ -276,8 +371,11 @@ extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const 
     NF_LAUNCHED("gather_sorted_kernel");
     cell_start_kernel<<<dim3((unsigned)((ncells + 1 + 255) / 256)), dim3(256), 0, s>>>(keys_out, n, ncells, cell_start);
     NF_LAUNCHED("cell_start_kernel");
+    const int Gc = (G + kCoarse - 1) / kCoarse;
+    coarse_count_kernel<<<dim3((unsigned)((coarse_cells(G) + 255) / 256)), dim3(256), 0, s>>>(cell_start, G, Gc, coarse_cnt);
+    NF_LAUNCHED("coarse_count_kernel");
     knn8_grid_kernel<<<dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s>>>(queries, n_queries, gp, sorted, cell_start,
-                                                                                  dist, idx_f32, idx_i32);
+                                                                                  coarse_cnt, dist, idx_f32, idx_i32);
     NF_LAUNCHED("knn8_grid_kernel");
     return NERFAIL_OK;
 }

@@ -110,3 +110,22 @@ def test_knn_pipeline_vs_reference_chain(golden):
     x_r, _ = gauss_gather(T(g['s']), wi_r, T(g['ori']), None)
     frac_r, worst_r = pipeline_deviation(N(x_r), g['ref_x'])
     assert frac_r == 0.0 and worst_r < 1e-5, (frac_r, worst_r)
+
+
+def test_knn_far_queries_on_view_geometry():
+    """Rendered-view geometry (synth.sphere_view_points: ~40 % surface pixels, ~60 % background pixels whose points sit
+    on the near plane, one to two units from every point of the set): the background queries leave the fine shell search
+    and finish on the coarse grid with box pruning. Grid result == brute force == oracle, bit for bit."""
+    from nerfail_amd.create_index_and_dist import index_and_dist
+    H = W = 96
+    S = np.stack([synth.sphere_view_points(H, W, th) for th in (-120., 0., 120.)]).reshape(-1, 3)
+    for th in (-171., 33.):
+        Q = synth.sphere_view_points(H, W, th)
+        grid = N(index_and_dist(T(Q), T(S), method='grid'))
+        brute = N(index_and_dist(T(Q), T(S), method='brute'))
+        assert np.array_equal(grid, brute), th
+        sel = np.concatenate([np.arange(0, 40), np.arange(H * W // 2, H * W // 2 + 40)])          # background + surface rows
+        od, oi = OK.knn8(Q.reshape(-1, 3)[sel], S)
+        assert np.array_equal(grid[0].reshape(-1, 8)[sel], od) and np.array_equal(grid[1].reshape(-1, 8)[sel], oi.astype(np.float32))
+        far = grid[0][..., 0] > 0.5
+        assert 0.3 < far.mean() < 0.8                                # the far-query path really ran
