@@ -235,6 +235,10 @@ int nerfail_gauss_bwd(const float* weight_and_index, const float* ori_img, const
  * ascending (b*P+p)*8+k order) is built once and reused by every attack epoch:
  *   row_ptr[Ns+1] int32, contrib[B*P*8] int32 (contribution id), w_sorted[B*P*8] (its weight).
  * workspace: nerfail_gauss_csr_workspace_bytes() bytes of scratch (0 = sizes unsupported). */
+/* Content fingerprint of n_items equally sized device buffers laid out back to back (32-bit words): out[2i] = sum of the
+ * words, out[2i+1] = sum of word * (1 + position mod 65521), modulo 2^64. Host code keys per-view inverted indices on it
+ * when a view's map arrives as an anonymous tensor (MyDataset.py:199-204 + DataLoader: a fresh tensor per iteration). */
+int nerfail_fingerprint(const void* data, int64_t words_per_item, int64_t n_items, uint64_t* out, void* stream);
 size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64_t P);
 /* row_of [B*P*8] int32: the destination row of every entry of the row-sorted list (contrib / w_sorted are in that order);
  * entries of weight 0 are sorted behind row_ptr[Ns] and never visited. */
@@ -249,6 +253,22 @@ int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* gra
                           const int32_t* row_ptr, const int32_t* contrib, const float* w_sorted, const int32_t* row_of,
                           int64_t Ns, int64_t B, int64_t P, float epsilon, float* scratch, int accumulate,
                           float* grad_spatial, void* stream);
+
+/* One view's inverted index (arrays of nerfail_gauss_csr_build with B = 1; contrib holds pixel*8 + k of THAT view). */
+typedef struct nerfail_view_index {
+    const int32_t* row_ptr;    /* [Ns+1] */
+    const int32_t* contrib;    /* [>= row_ptr[Ns]] */
+    const float* w_sorted;
+    const int32_t* row_of;
+} nerfail_view_index;
+/* The backward of a BATCH of views through their per-view indices (host table of n_views structs): per-pixel gradients of
+ * the whole batch in one pass, then one reduction per view, accumulated in view order (fixed: bitwise reproducible).
+ * ori_img / x / grad_* are [n_views*P, 4]; grad_spatial [Ns,4] is overwritten. A view's map is static, so its index is
+ * built once whatever batches it later appears in (the reference's DataLoader shuffles, AS:222-231).
+ * scratch: nerfail_gauss_bwd_scratch_floats(n_views, P, 1) floats. */
+int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
+                            const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
+                            float* scratch, float* grad_spatial, void* stream);
 
 /* The same backward for n_rhs (1..8) upstream gradients at once - the class-logit gradients of one DeepFool iteration
  * (deepfool.py:66-96 takes them one autograd.grad call at a time). grad_x_rgba: [n_rhs][B*P,4]; grad_spatial:

@@ -74,10 +74,12 @@ SIGNATURES = {
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),
+    'nerfail_fingerprint': (c_i, [c_p, c_i64, c_i64, c_p, c_p]),
     'nerfail_gauss_csr_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i64, c_i64]),
     'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_bwd_scratch_floats': (ctypes.c_size_t, [c_i64, c_i64, c_i]),
     'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
+    'nerfail_gauss_bwd_views': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     'nerfail_gauss_bwd_csr_multi': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     'nerfail_deepfool_norms_scratch_bytes': (ctypes.c_size_t, [c_i, c_i64]),
     'nerfail_deepfool_norms': (c_i, [c_p, c_i, c_i64, c_p, ctypes.c_size_t, c_p, c_p]),
@@ -86,6 +88,11 @@ SIGNATURES = {
     'nerfail_adam_step': (c_i, [c_p, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_p]),
 }
 
+
+
+class ViewIndexStruct(ctypes.Structure):
+    """struct nerfail_view_index (include/nerfail_hip.h)"""
+    _fields_ = [('row_ptr', c_p), ('contrib', c_p), ('w_sorted', c_p), ('row_of', c_p)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -131,7 +138,7 @@ def dev(t, name='tensor'):
         raise TypeError('%s must be a torch.Tensor' % name)
     if not t.is_cuda:
         raise RuntimeError('%s is on %s: nerfail_amd runs on the MI355X only (no CPU path)' % (name, t.device))
-    if t.dtype not in (torch.float32, torch.int32, torch.uint8):
+    if t.dtype not in (torch.float32, torch.int32, torch.uint8, torch.int64):
         raise TypeError('%s must be float32 (got %s)' % (name, t.dtype))
     if not t.is_contiguous():
         raise ValueError('%s must be contiguous' % name)

@@ -60,6 +60,7 @@ def packed_f16_T(net):
         return net._packed16T
     lib = _lib.load()
     n = lib.nerfail_mlp_f16_image_T_bytes(net.D, net.W, net._skip())
+    net.check_f16x3_range()
     keep = [_lib.f32c(p) for p in params]
     mp = _grads_struct(net, keep)
     buf = torch.empty((n,), dtype=torch.uint8, device=params[0].device)

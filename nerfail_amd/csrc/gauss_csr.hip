@@ -304,6 +304,24 @@ static size_t cub_temp_bytes(long n) {
     return bytes;
 }
 
+// Content fingerprint of B equally sized items (32-bit words): out[2b] = sum of the words, out[2b+1] = sum of word * (1 +
+// position mod 65521) - order-sensitive - both modulo 2^64. The host keys per-view inverted indices on it when a map arrives
+// as an anonymous tensor (a DataLoader hands out a fresh tensor every iteration: neither its address nor a version
+// counter says which view it is).
+__global__ __launch_bounds__(256) void fingerprint_kernel(const unsigned* __restrict__ data, long words, unsigned long long* __restrict__ out) {
+    const long b = blockIdx.y;
+    const unsigned* __restrict__ d = data + b * words;
+    unsigned long long s0 = 0, s1 = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long v = d[i];
+        s0 += v;
+        s1 += v * (unsigned long long)(1 + i % 65521);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out + 2 * b, s0); atomicAdd(out + 2 * b + 1, s1); }
+}
+
 static long seg_chunks(long B, long P) { return (B * P * 8 + kSegChunk - 1) / kSegChunk; }
 
 // one backward over the inverted index for C right-hand sides; g_pix [B*P][C] float4 is at the start of `scratch`
@@ -330,6 +348,22 @@ static int run_seg_reduce(const int32_t* row_ptr, const int32_t* contrib, const 
 }  // namespace nerfail
 
 using namespace nerfail;
+
+extern "C" int nerfail_fingerprint(const void* data, int64_t words_per_item, int64_t n_items, uint64_t* out, void* stream) {
+    NF_REQUIRE(words_per_item >= 0 && n_items >= 0 && n_items < 65536, "bad sizes");
+    if (n_items == 0) return NERFAIL_OK;
+    NF_REQUIRE(data != nullptr && out != nullptr, "NULL pointer");
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)n_items * 16, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    if (words_per_item == 0) return NERFAIL_OK;
+    long bx = (words_per_item + 255) / 256;
+    if (bx > 128) bx = 128;
+    fingerprint_kernel<<<dim3((unsigned)bx, (unsigned)n_items), dim3(256), 0, s>>>((const unsigned*)data, words_per_item,
+                                                                                  (unsigned long long*)out);
+    NF_LAUNCHED("fingerprint_kernel");
+    return NERFAIL_OK;
+}
 
 extern "C" size_t nerfail_gauss_csr_workspace_bytes(int64_t Ns, int64_t B, int64_t P) {
     if (Ns <= 0 || B <= 0 || P <= 0) return 0;
@@ -388,6 +422,41 @@ extern "C" int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const
         (float4*)scratch);
     NF_LAUNCHED("gauss_pixel_grad_kernel");
     return run_seg_reduce<1>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, accumulate, grad_spatial, s);
+}
+
+extern "C" int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
+                                       const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
+                                       float* scratch, float* grad_spatial, void* stream) {
+    NF_REQUIRE(Ns > 0 && P > 0 && n_views >= 1, "bad sizes");
+    NF_REQUIRE(ori_img && x && views && scratch && grad_spatial, "NULL pointer");
+    for (int v = 0; v < n_views; ++v)
+        NF_REQUIRE(views[v].row_ptr && views[v].contrib && views[v].w_sorted && views[v].row_of, "NULL pointer in a view index");
+    hipStream_t s = as_stream(stream);
+    const long n = (long)n_views * P;
+    // per-pixel gradients of the whole batch in one launch, then one reduction per view over its own index, in view order
+    gauss_pixel_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x, (const float4*)grad_x_rgba, n, epsilon,
+        (float4*)scratch);
+    NF_LAUNCHED("gauss_pixel_grad_kernel");
+    float* rec = scratch + (size_t)n * 4;                              // record area behind the batch's pixel gradients
+    for (int v = 0; v < n_views; ++v) {
+        const long chunks = ((seg_chunks(1, P) + 3) / 4) * 4;
+        const float4* g_pix = (const float4*)scratch + (size_t)v * P;
+        float4* rec_val = (float4*)rec;
+        int* rec_row = (int*)(rec_val + (size_t)2 * chunks);
+        if (v == 0) {
+            hipError_t e = hipMemsetAsync(grad_spatial, 0, (size_t)Ns * 16, s);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+        }
+        gauss_seg_reduce_kernel<1><<<dim3((unsigned)(chunks / 4)), dim3(256), 0, s>>>(
+            views[v].row_ptr + Ns, views[v].row_of, views[v].contrib, views[v].w_sorted, g_pix, 1, (float4*)grad_spatial, Ns,
+            rec_row, rec_val);
+        NF_LAUNCHED("gauss_seg_reduce_kernel");
+        gauss_seg_combine_kernel<1><<<dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s>>>(
+            rec_row, rec_val, chunks, 1, (float4*)grad_spatial, Ns);
+        NF_LAUNCHED("gauss_seg_combine_kernel");
+    }
+    return NERFAIL_OK;
 }
 
 extern "C" int nerfail_gauss_bwd_csr_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,

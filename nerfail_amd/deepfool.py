@@ -57,11 +57,13 @@ def deepfool(net_input, e, net, num_classes=8, max_iter=20, target_label: int = 
         if (target_label is not None) and int(cla_max_index) == int(target_label):
             break
 
-        multi = hasattr(net, 'logit_gradients') and getattr(net, 'deterministic', False) and num_classes <= 8
         if target_label is None:
             ks = [k for k in range(num_classes) if k != o]
         else:
             ks = [int(target_label)]
+        # the multi-RHS pass takes 2..8 logits ([o] + ks): with o >= num_classes all num_classes competitors remain (9 at
+        # num_classes = 8), with a single class none does - those cases iterate class by class like the reference
+        multi = hasattr(net, 'logit_gradients') and getattr(net, 'deterministic', False) and 2 <= len(ks) + 1 <= 8
         f_prime = (cla[0, ks] - (cla[0, o] + m2)).detach()                              # deepfool.py:79
         if multi:
             # all class gradients in one pass over the inverted index (K11 multi-RHS), then the step arithmetic in two

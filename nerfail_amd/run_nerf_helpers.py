@@ -150,12 +150,30 @@ class NeRF(nn.Module):
         n = lib.nerfail_mlp_f16_image_bytes(self.D, self.W, self._skip())
         if n == 0:
             raise NotImplementedError('unsupported NeRF shape D=%d W=%d' % (self.D, self.W))
+        self.check_f16x3_range()
         keep = []
         mp = self._mlp_params(keep)
         buf = torch.empty((n,), dtype=torch.uint8, device=params[0].device)
         _lib.check(lib.nerfail_mlp_pack_f16(mp, _lib.dev(buf), _lib.stream()))
         self._packed16, self._packed16_key = buf, key
         return buf
+
+    F16X3_MAX_WEIGHT = 60.0       # the split-precision image holds fp16(w * 2^10): |w| * 1024 must stay below 65504
+
+    def check_f16x3_range(self, every=64):
+        """The 'f16x3' kernels pre-scale the weights by 2^10 before the fp16 hi/lo split: a weight of magnitude >= ~64 would
+        become inf (and its lo part NaN) - silently wrong results in a mode advertised as fp32-equivalent. Checked on the
+        first pack and then every `every`-th one (one small device->host read; training re-packs after every step, and
+        Adam moves a weight by <= lr per step). Activations are bounded by the same mechanism only through the weights:
+        NeRF activations are O(1..100), fp16 range is 65504."""
+        self._f16_checks = getattr(self, '_f16_checks', -1) + 1
+        if self._f16_checks % every:
+            return
+        with torch.no_grad():
+            m = max(float(p.detach().abs().max()) for n_, p in self.named_parameters() if n_.endswith('weight'))
+        if not m < self.F16X3_MAX_WEIGHT:          # (also catches NaN)
+            raise ValueError("NeRF.precision = 'f16x3': max |weight| = %g is outside the range of the split-precision kernels "
+                             "(|w| < %g); use precision = 'f32'" % (m, self.F16X3_MAX_WEIGHT))
 
     def forward(self, x):
         x = _lib.f32c(x, _cuda())

@@ -134,3 +134,25 @@ def test_deepfool_step_kernels():
         assert np.array_equal(N(rot_d), rot)
     assert lib.nerfail_deepfool_norms_scratch_bytes(1, 10) == 0 and lib.nerfail_deepfool_norms_scratch_bytes(9, 10) == 0
     assert lib.nerfail_deepfool_norms(_lib.dev(Gd), 5, 70000, _lib.dev(scratch), 8, _lib.dev(norms2), _lib.stream()) != 0
+
+
+def test_deepfool_class_counts_outside_the_multi_rhs_range():
+    """the multi-RHS pass takes 2..8 logits. A classifier whose prediction lies outside range(num_classes)
+    leaves num_classes competitors (9 logits at num_classes = 8), num_classes = 1 leaves one: both must take the
+    class-by-class branch like the reference instead of raising."""
+    from nerfail_amd.GaussNet import gauss_net
+    from nerfail_amd.deepfool import deepfool
+    s, wi, ori = _small_problem(seed=9)
+    rs = np.random.RandomState(3)
+    w = T((rs.normal(size=(10, 48)) * 0.05).astype(np.float32))
+    bias = torch.zeros(10, device=dev())
+    bias[9] = 50.0                                              # prediction = class 9 >= num_classes = 8
+
+    class Cls(torch.nn.Module):
+        def forward(self, x):
+            return torch.nn.functional.adaptive_avg_pool2d(x, 4).reshape(x.shape[0], -1) @ w.t() + bias
+    net = gauss_net(dev(), 0.02, Cls(), 'my_model', epsilon=None)
+    rot, loop_i, ori_idx, cla_idx, s_new = deepfool((s, wi, ori), 1.0, net, num_classes=8, max_iter=2, m1=0.05, m2=0.5)
+    assert int(ori_idx) == 9 and loop_i == 2 and torch.isfinite(s_new).all()
+    rot, loop_i, _, _, s_new = deepfool((s, wi, ori), 1.0, net, num_classes=1, max_iter=1, m1=0.05, m2=0.5)
+    assert loop_i == 1 and torch.isfinite(s_new).all()

@@ -151,3 +151,18 @@ def test_split_gradients_vs_float64_truth():
     for k in truth:
         assert e['f32'][k] < 5e-3 and e['split'][k] < 5e-3, (k, e['f32'][k], e['split'][k])
         assert e['split'][k] < 10 * e['f32'][k] + 3e-4, (k, e['f32'][k], e['split'][k])
+
+
+def test_f16x3_rejects_weights_outside_its_range():
+    """the split-precision image stores fp16(w * 2^10); a weight of magnitude >= 64 would silently become inf.
+    The mirror refuses the mode instead (the exact-f32 kernel has no such limit)."""
+    from nerfail_amd.run_nerf import _mlp_points
+    _, net = hip_nerf(4, 64, 11, precision='f16x3')
+    with torch.no_grad():
+        net.pts_linears[1].weight[3, 5] = 70.0
+    pts = T(np.zeros((4, 8, 3), np.float32))
+    vd = T(np.tile(np.array([[0., 0., 1.]], np.float32), (4, 1)))
+    with pytest.raises(ValueError, match='f16x3'):
+        _mlp_points(net, pts, vd)
+    net.precision = 'f32'
+    assert torch.isfinite(_mlp_points(net, pts, vd)).all()
