@@ -11,6 +11,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import ops  # noqa: F401  (registers torch.ops.nerfail_mi.*)
 from .run_nerf_helpers import _cuda
 
 
@@ -372,7 +373,6 @@ class create_gauss_w(nn.Module):
         dai = _lib.f32c(dist_and_index_list, _cuda())
         if dai.dim() != 5 or dai.shape[1] != 2 or dai.shape[4] != 8:
             raise ValueError('dist_and_index_list must be [B,2,H,W,8] (CI:148-163)')
-        B, P = dai.shape[0], dai.shape[2] * dai.shape[3]
-        out = torch.empty_like(dai)
-        _lib.check(_lib.load().nerfail_gauss_weight(_lib.dev(dai), B, P, float(self.c), _lib.dev(out), _lib.stream()))
-        return out, dai[:, 0:1]
+        if not float(self.c) > 0:
+            raise _lib.NerfailError('create_gauss_w: c must be positive')
+        return torch.ops.nerfail_mi.gauss_weight(dai, float(self.c)), dai[:, 0:1]          # K9 as a registered op

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import ops  # noqa: F401  (registers torch.ops.nerfail_mi.*)
 from . import sharding
 from .run_nerf_helpers import _cuda
 
@@ -22,12 +23,11 @@ def igsm_step(spatial, grad, spatial_init, a=2.0, epsilon=32.0, targeted=False, 
     s0 = _lib.f32c(spatial_init, dev)
     if s.shape[-1] != 4 or g.shape != s.shape or s0.shape != s.shape:
         raise ValueError('spatial, grad and spatial_init must all be [..., 4] of the same shape')
-    if out is None:
-        out = torch.empty_like(s)
-    n = s.numel() // 4
-    _lib.check(_lib.load().nerfail_igsm_step(_lib.dev(s), _lib.dev(g), _lib.dev(s0), n, float(a), float(epsilon),
-                                             int(bool(targeted)), _lib.dev(out), _lib.stream()))
-    return out
+    res = torch.ops.nerfail_mi.igsm_step(s, g, s0, float(a), float(epsilon), bool(targeted))     # K12 as a registered op
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def perturbation_grad(net, spatial, weight_and_index, ori_img, label, batch_total=None, grad_fn=None):

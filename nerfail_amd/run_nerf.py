@@ -239,11 +239,17 @@ def _noise(shape, raw_noise_std, pytest, noise, dev):
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=False, pytest=False, noise=None):
     """RN:262-305 -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
     dev = _cuda()
+    raw_in = raw
     raw, z_vals, rays_d = _lib.f32c(raw, dev), _lib.f32c(z_vals, dev), _lib.f32c(rays_d, dev)
     R = z_vals.shape[0]
     rays = torch.zeros((R, _lib.RAY_FLOATS), dtype=torch.float32, device=dev)
     rays[:, 3:6] = rays_d
     nz = _noise(tuple(z_vals.shape), raw_noise_std, pytest, noise, dev)
+    if nz is None:
+        # the registered op (torch.ops.nerfail_mi.composite): differentiable w.r.t. `raw` like the reference's function
+        from . import ops  # noqa: F401
+        raw_g = raw_in.to(dev).float().contiguous() if isinstance(raw_in, torch.Tensor) and raw_in.requires_grad else raw
+        return tuple(torch.ops.nerfail_mi.composite(raw_g, z_vals, rays, bool(white_bkgd)))
     return _composite(raw, z_vals, rays, nz, white_bkgd)[:5]
 
 
