@@ -120,3 +120,52 @@ def test_pipeline_through_files(tmp_path):
     d = N(s - s0)
     assert np.array_equal(d[..., 3], np.zeros_like(d[..., 3])) and np.abs(d[..., :3]).max() <= 4.0 and np.abs(d).max() > 0
     assert np.isfinite(float(loss))
+
+
+def test_retrain_on_attacked_data_round_trip(tmp_path):
+    """SURVEY 8f N3 - the paper's closing loop at toy size: a Blender-format scene on disk -> load_blender_data -> a few
+    training steps (RN:746-801) -> adversarial versions of the TRAIN images written as PNGs (what attack_NeRFail_S.py's last
+    epoch does, AS:394-403) -> load_blender_data(train_dir=...) (LB:62-63) -> training continues on the attacked images."""
+    from PIL import Image
+    from test_load_blender import write_toy_scene
+    from nerfail_amd import run_nerf as RN
+    from nerfail_amd.load_blender import load_blender_data, training_images, train_step
+    root = str(tmp_path / 'scene')
+    raw = write_toy_scene(root, H=16, W=16, n=(3, 2, 2), seed=3)
+    images, poses, render_poses, hwf, i_split = load_blender_data(root)
+    i_train = i_split[0]
+    Hh, Ww, focal = hwf
+    K = np.array([[focal, 0, 0.5 * Ww], [0, focal, 0.5 * Hh], [0, 0, 1]])
+    logs = str(tmp_path / 'logs')
+    os.makedirs(os.path.join(logs, 'blender_paper_toy'))
+    args = _args(logs)
+    torch.manual_seed(0)
+    render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer = RN.create_nerf(args)
+    assert start == 0
+    with torch.no_grad():       # a freshly initialised NeRF has sigma <= 0 nearly everywhere (no density, no gradient):
+        for net in (render_kwargs_train['network_fn'], render_kwargs_train['network_fine']):
+            net.alpha_linear.bias += 0.5                       # the same nudge the fixtures use (SURVEY.md section 7)
+    imgs = training_images(images, white_bkgd=True)
+    rng = np.random.RandomState(0)
+    w0 = N(grad_vars[0]).copy()
+    losses = [train_step(imgs, poses, i_train, hwf, K, render_kwargs_train, optimizer, step, N_rand=128, rng=rng)[0]
+              for step in range(1, 4)]
+    assert all(np.isfinite(losses)) and np.abs(N(grad_vars[0]) - w0).max() > 0
+    # "attack": a bounded perturbation of the train images, saved under the SAME file names in another directory
+    adv_dir = str(tmp_path / 'adv_train')
+    os.makedirs(adv_dir)
+    adv = raw['train'].astype(np.int32)
+    adv[..., :3] = np.clip(adv[..., :3] + np.random.RandomState(1).randint(-32, 33, adv[..., :3].shape), 0, 255)
+    for i in range(3):
+        Image.fromarray(adv[i].astype(np.uint8), 'RGBA').save(os.path.join(adv_dir, 'r_%d.png' % i))
+    images2, poses2, _, hwf2, i_split2 = load_blender_data(root, train_dir=adv_dir)
+    imgs2 = training_images(images2, white_bkgd=True, train_dir=adv_dir)
+    assert imgs2.shape == imgs.shape and np.array_equal(imgs2[3:], imgs[3:]) and not np.array_equal(imgs2[:3], imgs[:3])
+    rng = np.random.RandomState(0)
+    l2, psnr, lr = train_step(imgs2, poses2, i_split2[0], hwf2, K, render_kwargs_train, optimizer, 4, N_rand=128, rng=rng)
+    assert np.isfinite(l2) and np.isfinite(psnr) and 0 < lr <= 5e-4
+    # the renderer still renders after the weight updates (packed images follow the parameter versions)
+    with torch.no_grad():
+        rgb, disp, acc, extras = RN.render(16, 16, K, chunk=256, c2w=torch.from_numpy(poses2[0, :3, :4]), near=2., far=6.,
+                                           **{k: v for k, v in render_kwargs_test.items()})
+    assert tuple(rgb.shape) == (16, 16, 3) and torch.isfinite(rgb).all()
