@@ -132,7 +132,6 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
     const MlpLayout& L = a.lay;
     const long ntiles = (a.M + 31) / 32;
     const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);
-    const unsigned long long nf_c0 = (NF_FWD_ABLATE == 9) ? clock64() : 0, nf_w0 = (NF_FWD_ABLATE == 9) ? wall_clock64() : 0;
 
     for (long rnd = 0; rnd < nrounds; ++rnd) {
         const long tile = (rnd * gridDim.x + blockIdx.x) * 4 + wave;
@@ -142,12 +141,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
 
         // ---- B operands of the encoding parts, in registers
         float emb[4 * kEmbQuads], demb[4 * kDirQuads];
-        if (NF_FWD_ABLATE == 3) {
-#pragma unroll
-            for (int i = 0; i < 4 * kEmbQuads; ++i) emb[i] = 0.25f * (float)(lane & 3);
-#pragma unroll
-            for (int i = 0; i < 4 * kDirQuads; ++i) demb[i] = 0.5f;
-        } else if (a.xemb == nullptr) {
+        if (a.xemb == nullptr) {
             const float px[3] = {a.pts[3 * s], a.pts[3 * s + 1], a.pts[3 * s + 2]};
             const float* vd = a.viewdirs + 3 * (s / a.spr);
             const float vx[3] = {vd[0], vd[1], vd[2]};
@@ -287,10 +281,6 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
         }
         if (h == 0 && sraw < a.M)
             reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);
-    }
-    if (NF_FWD_ABLATE == 9 && threadIdx.x == 0) {   // clock probe: shader cycles / 100 MHz wall ticks of this workgroup
-        reinterpret_cast<unsigned long long*>(a.raw)[2 * blockIdx.x] = clock64() - nf_c0;
-        reinterpret_cast<unsigned long long*>(a.raw)[2 * blockIdx.x + 1] = wall_clock64() - nf_w0;
     }
 }
 

@@ -456,9 +456,6 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_kernel(WArgs a) {
 // lane), so the XOR swizzle that makes the readers' ds_read_b128 conflict-free is applied to the per-lane SOURCE
 // address: 16-byte piece (channel c, quarter q) sits at position 4c + (q ^ ((c >> 2) & 3)). A reader lane (c, kh)
 // takes quarters 2kh and 2kh+1 = samples 8kh .. 8kh+7 of the step, exactly dw_task_bf16's k mapping.
-#ifndef NF_DW_ABLATE
-#define NF_DW_ABLATE 0          // timing experiments (tools/ablate_dw.py): 1 no LDS-DMA, 2 no hi/lo split, 3 no MFMA
-#endif
 #ifndef NF_DW_AUX
 #define NF_DW_AUX 0             // cache policy bits of the LDS-DMA loads (2 = nt)
 #endif
@@ -522,10 +519,7 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
             const int pc = wave + 4 * i;
             const int ps = pc < NPIECE ? pc : pc - 4;                   // padding piece: same parity, valid source
             const float* src = ps < 2 * LA ? zb + (ps >> 1) * 1024 : xb + ((ps - 2 * LA) >> 1) * 1024;
-            if (NF_DW_ABLATE == 4)      // timing experiment: plane-major addressing [slot][tile] (wrong data, in bounds)
-                src = ps < 2 * LA ? a.dz + ((size_t)(g.dz_slot0 + (ps >> 1)) * a.ntiles + t) * 1024 + ks * 512 + lane_src
-                                  : a.acts + ((size_t)(g.x_slot0 + ((ps - 2 * LA) >> 1)) * a.ntiles + t) * 1024 + ks * 512 + lane_src;
-            if (NF_DW_ABLATE != 1) __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + pc * 256), 16, 0, NF_DW_AUX);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + pc * 256), 16, 0, NF_DW_AUX);
         }
     };
     // Operands of a step are read from LDS into registers one step AHEAD (raw[..]), so the ds_read latency and the
@@ -559,15 +553,13 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
             if (do_bias) rowsum[m] += (rawA[m][0][0] + rawA[m][0][1]) + (rawA[m][0][2] + rawA[m][0][3]) +
                                       (rawA[m][1][0] + rawA[m][1][1]) + (rawA[m][1][2] + rawA[m][1][3]);
             if constexpr (BF16) {
-                if (NF_DW_ABLATE == 2) { ah[m] = __builtin_bit_cast(u32x4b, rawA[m][0]); al[m] = __builtin_bit_cast(u32x4b, rawA[m][1]); }
-                else split_bf16(rawA[m][0], rawA[m][1], ah[m], al[m]);
+                split_bf16(rawA[m][0], rawA[m][1], ah[m], al[m]);
             } else { av[m][0] = rawA[m][0]; av[m][1] = rawA[m][1]; }
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             if constexpr (BF16) {
-                if (NF_DW_ABLATE == 2) { bh[n] = __builtin_bit_cast(u32x4b, rawB[n][0]); bl[n] = __builtin_bit_cast(u32x4b, rawB[n][1]); }
-                else split_bf16(rawB[n][0], rawB[n][1], bh[n], bl[n]);
+                split_bf16(rawB[n][0], rawB[n][1], bh[n], bl[n]);
             } else { bv[n][0] = rawB[n][0]; bv[n][1] = rawB[n][1]; }
         }
         wait_vmcnt<(NS - 3) * G>();                                     // this wave's pieces of stage s+1 have landed
@@ -583,8 +575,7 @@ __device__ __forceinline__ void dw_group_lds(const LArgs& a, const LGroup& g, fl
                     for (int n = 0; n < NB; ++n) {
                         const bf8 A_ = __builtin_bit_cast(bf8, x == 2 ? al[m] : ah[m]);
                         const bf8 B_ = __builtin_bit_cast(bf8, x == 1 ? bl[n] : bh[n]);
-                        if (NF_DW_ABLATE != 3) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[m][n], 0, 0, 0);
-                        else acc[m][n][(x * 5 + m + n) & 15] += __uint_as_float(A_[0] == B_[1] ? 1u : 0u);   // keep the operands alive
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[m][n], 0, 0, 0);
                     }
         } else {
             // exact-f32 form: the 8 samples a lane holds are 8 k-steps of v_mfma_f32_32x32x2_f32 (k = (step, kh) <-> sample
@@ -636,7 +627,6 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_lds_kernel(LArgs 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long total = a.cum[a.ngroups];
-    const unsigned long long nf_w0 = (NF_DW_ABLATE == 9) ? wall_clock64() : 0;
     const long lo = total / gridDim.x * blockIdx.x + (total % gridDim.x) * blockIdx.x / gridDim.x;
     const long hi = total / gridDim.x * (blockIdx.x + 1) + (total % gridDim.x) * (blockIdx.x + 1) / gridDim.x;
     for (int g = 0; g < a.ngroups; ++g) {
@@ -656,8 +646,6 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_weights_lds_kernel(LArgs 
             default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;
         }
     }
-    if (NF_DW_ABLATE == 9 && threadIdx.x == 0)      // timing probe: this workgroup's busy time in 10 ns ticks, over dz[0..]
-        reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;
 }
 
 static int cu_count() {

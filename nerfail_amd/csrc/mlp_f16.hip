@@ -182,9 +182,6 @@ __device__ __forceinline__ void load_bias_scaled(f32x16 (&acc)[OT], const float*
 
 // The weight stream of one workgroup. CH = fragments per chunk, PER_T = fragments each thread moves per chunk.
 // A chunk holds NT (hi, lo) fragment pairs: pair p = [step-in-chunk][tile]; "first half" = pairs 0..NT/2-1.
-#ifndef NF_F16_ABLATE
-#define NF_F16_ABLATE 0     // timing experiments (tools/ablate.py): 1 no barrier, 2 no weight staging, 3 neither
-#endif
 template <int NT>
 struct WStream {
     static constexpr int CH = NT * 2 * 64;
@@ -249,14 +246,11 @@ __device__ __forceinline__ void f16_part(f32x16 (&acc)[NT / SPC], WStream<NT>& w
         // ---- phase A
         u32x4 fb[HP][2];
         read_half<NT>(fb, rp, c & 1, 1);            // second half of chunk c
-        if (NF_F16_ABLATE != 2 && NF_F16_ABLATE != 3) {
 #pragma unroll
-            for (int i = 0; i < PER_T; ++i) wp[((c + 1) & 1) * CH + i * 256] = w.st[(c + 1) & 1][i];   // chunk c+1 -> LDS
-            stream_load<NT>(w, w.st[(c + 1) & 1]);      // chunk c+3 -> the stage just freed
-        }
+        for (int i = 0; i < PER_T; ++i) wp[((c + 1) & 1) * CH + i * 256] = w.st[(c + 1) & 1][i];   // chunk c+1 -> LDS
+        stream_load<NT>(w, w.st[(c + 1) & 1]);      // chunk c+3 -> the stage just freed
         if (live) mfma_half(c, 0, w.fa);
-        if (NF_F16_ABLATE != 1 && NF_F16_ABLATE != 3)
-            __syncthreads();                        // chunk c+1 visible; nobody reads slot (c+1)&1's old content any more
+        __syncthreads();                        // chunk c+1 visible; nobody reads slot (c+1)&1's old content any more
         // ---- phase B
         read_half<NT>(w.fa, rp, (c + 1) & 1, 0);    // first half of chunk c+1 (possibly the next part's chunk 0)
         if (live) mfma_half(c, 1, fb);

@@ -178,18 +178,10 @@ static inline void make_layout_T(int D, int NT, MlpLayoutT& L) {
 }
 
 // ---- device helpers shared by the forward and backward kernels -------------------------------------------
-#ifndef NF_FWD_ABLATE
-#define NF_FWD_ABLATE 0     // timing experiments (tools/ablate.py): 1 no bias loads, 2 no exposed first weight quad, 3 no encoding, 4 no weight stream (registers rotate), 5 weight stream re-reads quads 0/1 (L1-hot), 9 clock probe
-#endif
 template <int OT>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __restrict__ b, int h) {
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
-        if (NF_FWD_ABLATE == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            continue;
-        }
         const f32x4* p = reinterpret_cast<const f32x4*>(b + (t * 2 + h) * 16);
         const f32x4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
         acc[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
@@ -207,7 +199,7 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[OT], const float* __rest
 #endif
 // What the exact-f32 forward kernel loses against the 154.8 TFLOP/s the bare MFMA loop sustains on this chip (clock
 // 2.387 GHz inside the kernel, no throttling - tools/clockprobe, tools/fwd_clock.py), measured by ablation
-// (tools/ablate.py, NF_FWD_ABLATE) at 1.57 M samples, 14.14 ms = 132 TFLOP/s:
+// (round-1 experiment builds, see tools/README.md) at 1.57 M samples, 14.14 ms = 132 TFLOP/s:
 //   weight stream served from L1 instead of L2 (re-reading quads 0/1)   13.13 ms   -> 6.5 % is L2 -> CU delivery
 //   no weight stream at all (registers rotate)                          13.23 ms      (i.e. not instruction issue)
 //   no positional encoding                                              13.92 ms   -> 2 %
@@ -227,15 +219,13 @@ __device__ __forceinline__ void mfma_part(f32x16 (&acc)[OT], const float* __rest
 #pragma unroll
     for (int p = 0; p < PF && p < NQ; ++p)
 #pragma unroll
-        for (int t = 0; t < OT; ++t) ring[p][t] = (NF_FWD_ABLATE == 2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : wp[(p * OT + t) * 64];
+        for (int t = 0; t < OT; ++t) ring[p][t] = wp[(p * OT + t) * 64];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (q + PF < NQ) {
 #pragma unroll
             for (int t = 0; t < OT; ++t)
-                ring[(q + PF) % RING][t] = (NF_FWD_ABLATE == 4) ? (f32x4){ring[q % RING][t][1], ring[q % RING][t][2], ring[q % RING][t][3], ring[q % RING][t][0]}
-                                                                : (NF_FWD_ABLATE == 6) ? __builtin_nontemporal_load(&wp[((q + PF) * OT + t) * 64])
-                                                                : wp[(((NF_FWD_ABLATE == 5) ? (q & 1) : (q + PF)) * OT + t) * 64];
+                ring[(q + PF) % RING][t] = wp[((q + PF) * OT + t) * 64];
             // Pin the software pipeline: nothing may be scheduled across this point, so the loads of quad q+PF stay
             // AHEAD of the 4*OT MFMAs of quad q (under register pressure the scheduler otherwise sinks them next to
             // their use and every quad waits vmcnt(0) on an exposed L2 round trip).

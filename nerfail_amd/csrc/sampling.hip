@@ -6,8 +6,9 @@
 //   - cdf: torch's CPU cumsum accumulates in double and rounds each prefix to float; the wave scan
 //     here runs in double too, so prefixes agree to the last float bit for equal pdf inputs.
 //   - searchsorted(right=True): 6-step binary search in LDS.
-//   - sort(cat(z_coarse, z_samples)): rank sort (each element counts smaller elements; ties by
-//     position), conflict-free broadcast reads; values only, so tie order cannot change the output.
+//   - sort(cat(z_coarse, z_samples)): a binary-search merge when both halves are already ascending (every
+//     perturb = 0 render), else a rank sort (each element counts smaller elements; ties by position);
+//     values only, so neither the algorithm nor the tie order can change the output.
 #include "common.h"
 
 namespace nerfail {
@@ -15,14 +16,23 @@ namespace nerfail {
 constexpr int kMaxBins = 256;     // cdf entries per ray (n_coarse - 1 <= 255)
 constexpr int kMaxMerged = 512;   // n_coarse + n_fine
 
+// #{i < n : a[i] < v} (STRICT) or #{a[i] <= v} for ascending a[0..n-1]; top = a power of two >= (n + 1) / 2.
+template <bool STRICT>
+__device__ __forceinline__ int count_sorted(const float* a, int n, int top, float v) {
+    int pos = 0;
+    for (int step = top; step > 0; step >>= 1) {
+        const int p = pos + step;
+        const float o = a[min(p, n) - 1];
+        if (p <= n && (STRICT ? o < v : o <= v)) pos = p;
+    }
+    return pos;
+}
+
 // Inverse-CDF sample for one u (RH:227-241). cdf[0..nb-1] (cdf[0] = 0), bins[0..nb-1] in LDS.
 __device__ __forceinline__ float invert_cdf(const float* cdf, const float* bins, int nb, float u) {
-    // inds = number of cdf entries <= u (searchsorted right=True)
-    int lo = 0, hi = nb;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
-    }
+    // inds = number of cdf entries <= u (searchsorted right=True); cdf ascends, so a branch-free descent over
+    // power-of-two steps counts them (every lane runs the same 8 steps: no exec-mask loop)
+    const int lo = count_sorted<false>(cdf, nb, 1 << (31 - __clz(nb)), u);
     const int below = max(0, lo - 1);
     const int above = min(nb - 1, lo);
     const float cb = cdf[below], ca = cdf[above];
@@ -33,19 +43,30 @@ __device__ __forceinline__ float invert_cdf(const float* cdf, const float* bins,
     return __fadd_rn(bb, __fmul_rn(t, __fsub_rn(ba, bb)));
 }
 
-// Builds cdf (nb entries) in LDS from nb-1 weights supplied by `wfn(i)`; all 64 lanes participate.
-template <typename WFn>
-__device__ __forceinline__ void build_cdf(float* cdf, int nb, int lane, WFn wfn) {
+// The nb-1 <= 255 weights of a ray, lane-strided in registers (entry c of lane l = weight 64 c + l): loaded once, at
+// the top of the kernel, so that the HBM round trip overlaps the other loads instead of sitting between two phases.
+constexpr int kWRegs = (kMaxBins - 1 + 63) / 64;
+__device__ __forceinline__ void load_weights(float (&wr)[kWRegs], const float* __restrict__ w, int nw, int lane) {
+#pragma unroll
+    for (int c = 0; c < kWRegs; ++c) wr[c] = (64 * c + lane < nw) ? w[64 * c + lane] : 0.0f;
+}
+
+// Builds cdf (nb entries) in LDS from the nb-1 weights in wr; all 64 lanes participate.
+__device__ __forceinline__ void build_cdf(float* cdf, int nb, int lane, const float (&wr)[kWRegs]) {
     const int nw = nb - 1;
     // pass 1: sum of (w + 1e-5)
     float part = 0.f;
-    for (int i = lane; i < nw; i += 64) part += __fadd_rn(wfn(i), 1e-5f);
+#pragma unroll
+    for (int c = 0; c < kWRegs; ++c)
+        if (64 * c + lane < nw) part += __fadd_rn(wr[c], 1e-5f);
     const float total = wave_sum(part);
     // pass 2: running prefix in double across 64-wide chunks
     double carry = 0.0;
-    for (int c = 0; c < nw; c += 64) {
-        const int i = c + lane;
-        const float pdf = (i < nw) ? __fdiv_rn(__fadd_rn(wfn(i), 1e-5f), total) : 0.0f;
+#pragma unroll
+    for (int c = 0; c < kWRegs; ++c) {
+        if (64 * c >= nw) break;                     // wave-uniform
+        const int i = 64 * c + lane;
+        const float pdf = (i < nw) ? __fdiv_rn(__fadd_rn(wr[c], 1e-5f), total) : 0.0f;
         const double incl = wave_scan_add_f64((double)pdf, lane) + carry;
         if (i < nw) cdf[i + 1] = (float)incl;
         carry = __shfl(incl, 63, 64);
@@ -63,9 +84,10 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(const float* __restrict
     if (ray >= n_rays) return;
     float* cdf = s_cdf[wv];
     float* bn = s_bins[wv];
-    const float* w = weights + ray * (nb - 1);
+    float wr[kWRegs];
+    load_weights(wr, weights + ray * (nb - 1), nb - 1, lane);
     for (int i = lane; i < nb; i += 64) bn[i] = bins[ray * nb + i];
-    build_cdf(cdf, nb, lane, [&](int i) { return w[i]; });
+    build_cdf(cdf, nb, lane, wr);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave visible to its reads
     for (int k = lane; k < n; k += 64) {
@@ -80,33 +102,34 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
                                                           const float* __restrict__ u, int u_is_row, int nf,
                                                           float* __restrict__ z_samples, float* __restrict__ z_fine,
                                                           float* __restrict__ pts, float* __restrict__ z_std) {
-    __shared__ float s_cdf[4][kMaxBins];
-    __shared__ float s_bins[4][kMaxBins];
+    __shared__ float s_cb[4][2 * kMaxBins];                                // cdf | bins
     __shared__ __attribute__((aligned(16))) float s_in[4][kMaxMerged];
-    __shared__ float s_out[4][kMaxMerged];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long ray = (long)blockIdx.x * 4 + wv;
     if (ray >= n_rays) return;
-    float* cdf = s_cdf[wv];
-    float* bn = s_bins[wv];
+    float* cdf = s_cb[wv];
+    float* bn = s_cb[wv] + kMaxBins;
     float* zin = s_in[wv];
-    float* zout = s_out[wv];
     const int nb = nc - 1;            // z_vals_mid has nc-1 entries; weights[...,1:-1] has nc-2
     const int nt = nc + nf;
     const float* zc = z_coarse + ray * nc;
-    const float* w = weights + ray * nc;
+    float wr[kWRegs];
+    load_weights(wr, weights + ray * nc + 1, nb - 1, lane);                                       // weights[...,1:-1]
+    const float* rr = rays + NERFAIL_RAY_FLOATS * ray;
+    const float ox = rr[0], oy = rr[1], oz = rr[2], dx = rr[3], dy = rr[4], dz = rr[5];
+    const float u0 = (lane < nf) ? (u_is_row ? u[lane] : u[ray * nf + lane]) : 0.0f;             // first sweep's draws
 
     for (int i = lane; i < nc; i += 64) zin[i] = zc[i];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     for (int i = lane; i < nb; i += 64) bn[i] = __fmul_rn(0.5f, __fadd_rn(zin[i + 1], zin[i]));   // RN:392
-    build_cdf(cdf, nb, lane, [&](int i) { return w[i + 1]; });                                    // weights[...,1:-1]
+    build_cdf(cdf, nb, lane, wr);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
 
     float ssum = 0.f;
     for (int k = lane; k < nf; k += 64) {
-        const float uk = u_is_row ? u[k] : u[ray * nf + k];
+        const float uk = (k == lane) ? u0 : (u_is_row ? u[k] : u[ray * nf + k]);
         const float zs = invert_cdf(cdf, bn, nb, uk);
         zin[nc + k] = zs;
         if (z_samples != nullptr) z_samples[ray * nf + k] = zs;
@@ -125,7 +148,44 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
 
-    // rank sort: rank(e) = #{j : z_j < z_e or (z_j == z_e and j < e)}
+    // sort(cat(z_coarse, z_samples)) (RN:397) - values only, so every correct sort writes the same row.
+    // Both halves are normally already ascending (z_vals always; z_samples whenever u is: perturb = 0 uses
+    // linspace): then an element's place in the merged row is its own index plus a binary search in the
+    // OTHER half (~20 dependent LDS reads per lane instead of the 3 x 48 float4 sweeps of the rank sort below,
+    // which made this kernel VALU-bound: 3.1 ms per 640 000-ray view against 0.3 ms of HBM time).
+    int ordered = 1;
+    for (int i = lane; i < nt - 1; i += 64)
+        if (i != nc - 1) ordered &= (int)(zin[i] <= zin[i + 1]);              // false for NaN: those rows take the rank sort
+    // The row is written straight from the ranks: 4-byte stores scattered inside the ray's own 768 + 2304 contiguous
+    // bytes (L2 combines the lines). Measured at 640 000 rays: 0.97 ms; staging the sorted row in LDS for 16-byte
+    // stores: 1.09 ms (the kernel is instruction-issue bound, ~900 wave instructions per ray, not store bound).
+    float* zrow = z_fine + ray * nt;
+    float* prow = pts + 3 * ray * nt;
+    auto emit = [&](int rank, float z) {
+        zrow[rank] = z;
+        prow[3 * rank + 0] = mul_add_rn(dx, z, ox);               // pts = o + d z (RN:399)
+        prow[3 * rank + 1] = mul_add_rn(dy, z, oy);
+        prow[3 * rank + 2] = mul_add_rn(dz, z, oz);
+    };
+    if (__all(ordered)) {                                                     // wave-uniform
+        const int top = 1 << (31 - __clz(max(nc, nf)));
+        for (int e = lane; e < nt; e += 64) {
+            const float v = zin[e];
+            const bool is_c = e < nc;
+            // coarse i: i + #{samples < v};  sample j: j + #{coarse <= v}  (a stable merge, coarse first on ties)
+            const float* other = is_c ? zin + nc : zin;
+            const int n = is_c ? nf : nc;
+            int lo = 0;
+            for (int step = top; step > 0; step >>= 1) {
+                const int p = lo + step;
+                const float o = other[min(p, n) - 1];
+                if (p <= n && (is_c ? (o < v) : (o <= v))) lo = p;
+            }
+            emit((is_c ? e : e - nc) + lo, v);
+        }
+        return;
+    }
+    // general case (random u: training with perturb = 1): rank(e) = #{j : z_j < z_e or (z_j == z_e and j < e)}
     for (int e = lane; e < nt; e += 64) {
         const float v = zin[e];
         int rank = 0;
@@ -138,20 +198,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
             rank += (q.z < v) || (q.z == v && j + 2 < e);
             rank += (q.w < v) || (q.w == v && j + 3 < e);
         }
-        zout[rank] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-
-    const float* rr = rays + NERFAIL_RAY_FLOATS * ray;
-    const float ox = rr[0], oy = rr[1], oz = rr[2], dx = rr[3], dy = rr[4], dz = rr[5];
-    for (int i = lane; i < nt; i += 64) {
-        const float z = zout[i];
-        z_fine[ray * nt + i] = z;
-        float* p = pts + 3 * (ray * nt + i);
-        p[0] = mul_add_rn(dx, z, ox);
-        p[1] = mul_add_rn(dy, z, oy);
-        p[2] = mul_add_rn(dz, z, oz);
+        emit(rank, v);
     }
 }
 

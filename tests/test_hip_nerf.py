@@ -237,6 +237,42 @@ def test_sample_fine_sorted_and_matches_oracle():
         assert rel_err(N(r[k]), ref[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('case', ['ordered_row_u', 'random_u', 'ties', 'descending_coarse'])
+def test_sample_fine_merge_is_the_sort(case):
+    """nerfail_sample_fine's merged row (RN:397 sort(cat(z_vals, z_samples))) is bit for bit numpy's sort of the same
+    values, and pts = o + d z, through both of its branches: the binary-search merge (both halves ascending) and the rank
+    sort (random u; a descending z_vals); ties between and inside the halves (zero weights: repeated samples)."""
+    from nerfail_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    R, nc, nf = 37, 64, 128
+    rays = synth.ray_batch(R, seed=3)
+    zc = np.sort(rs.uniform(2, 6, size=(R, nc)).astype(np.float32), -1)
+    w = rs.uniform(0, 1, size=(R, nc)).astype(np.float32)
+    u, row = np.ascontiguousarray(O.torch_linspace01(nf), np.float32), 1
+    if case == 'random_u':
+        u, row = rs.uniform(size=(R, nf)).astype(np.float32), 0
+    if case == 'ties':
+        w[:, 5:40] = 0.0                        # flat cdf stretches: many equal samples
+        w[3] = 0.0                              # a ray nothing was hit on
+        zc[:, 10:14] = zc[:, 10:11]             # equal coarse depths
+    if case == 'descending_coarse':
+        zc = zc[:, ::-1].copy()
+    zs, zf = torch.empty((R, nf), device=dev()), torch.empty((R, nc + nf), device=dev())
+    pts, zstd = torch.empty((R, nc + nf, 3), device=dev()), torch.empty((R,), device=dev())
+    rays_d, zc_d, w_d, u_d = T(rays), T(zc), T(w), T(u)          # named: the pointers must outlive the call
+    _lib.check(lib.nerfail_sample_fine(_lib.dev(rays_d), R, _lib.dev(zc_d), _lib.dev(w_d), nc, _lib.dev(u_d), row, nf,
+                                       _lib.dev(zs), _lib.dev(zf), _lib.dev(pts), _lib.dev(zstd), _lib.stream()))
+    merged = np.sort(np.concatenate([zc, N(zs)], -1), -1)
+    assert np.array_equal(N(zf), merged)
+    o, d = rays[:, None, 0:3], rays[:, None, 3:6]
+    assert np.array_equal(N(pts), (d * merged[..., None]).astype(np.float32) + o)
+    if case != 'descending_coarse':
+        bins = 0.5 * (zc[:, 1:] + zc[:, :-1])
+        ref = O.sample_pdf(bins, w[:, 1:-1], nf, u=None if row else u)
+        _check_samples(N(zs), ref, np.broadcast_to(u, ref.shape), bins)        # u = 1 may land one bin over (RH:239)
+
+
 def test_cpu_tensors_are_moved_not_computed_on_cpu():
     """Inputs on the CPU are copied to the GPU; outputs always live on the GPU (there is no CPU path)."""
     from nerfail_amd.run_nerf import raw2outputs

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Per-workgroup busy time of the LDS-staged weight-gradient kernel (needs the NF_DW_ABLATE=9 build of tools/ablate.py:
+"""Per-workgroup busy time of the LDS-staged weight-gradient kernel (needs `python tools/experiment.py dw_clock`:
 every workgroup writes its wall-clock ticks over the start of dz). Shows how well the cost model balances the grid."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
-os.environ['NERFAIL_HIP_LIB'] = os.path.join(ROOT, 'nerfail_amd', 'lib', 'libnerfail_hip_NF_DW_ABLATE_9.so')
+os.environ['NERFAIL_HIP_LIB'] = os.path.join(ROOT, 'nerfail_amd', 'lib', 'libnerfail_hip_exp_dw_clock.so')
 os.environ['NERFAIL_DW_KERNEL'] = 'lds'
 import synth
 from nerfail_amd import _lib, _train

@@ -69,6 +69,27 @@ EXPERIMENTS = {
          '        for (int e = 0; e < 4; ++e) {\n#pragma unroll\n            for (int t = 0; t < HSP; ++t) {\n                mf(t, e, cur[t][e]);'),
         ('            if (t == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n                prefetch();',
          '            if (e == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n                prefetch();')], []),
+    # clock probes of the register-streamed forward kernel and of the LDS-staged weight-gradient kernel (tools/fwd_clock.py,
+    # tools/dw_balance.py read the stamps; outputs destroyed)
+    'fwd_clock': ('mlp.hip', [
+        ('    const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);\n\n    for (long rnd = 0; rnd < nrounds; ++rnd) {\n        const long tile = (rnd * gridDim.x + blockIdx.x) * 4 + wave;\n        if (tile >= ntiles) break;     // wave-uniform; waves are fully independent (no barriers)\n',
+         '    const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);\n    const unsigned long long nf_c0 = clock64(), nf_w0 = wall_clock64();\n\n    for (long rnd = 0; rnd < nrounds; ++rnd) {\n        const long tile = (rnd * gridDim.x + blockIdx.x) * 4 + wave;\n        if (tile >= ntiles) break;     // wave-uniform; waves are fully independent (no barriers)\n'),
+        ('            reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);\n    }\n}\n',
+         '            reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);\n    }\n'
+         '    if (threadIdx.x == 0) {\n'
+         '        reinterpret_cast<unsigned long long*>(a.raw)[2 * blockIdx.x] = clock64() - nf_c0;\n'
+         '        reinterpret_cast<unsigned long long*>(a.raw)[2 * blockIdx.x + 1] = wall_clock64() - nf_w0;\n    }\n}\n')], []),
+    'dw_clock': ('mlp_bwd.hip', [
+        ('    __shared__ __attribute__((aligned(16))) float smem[kLdsStages * kLdsStageFloats];\n    const int lane = threadIdx.x & 63;\n',
+         '    __shared__ __attribute__((aligned(16))) float smem[kLdsStages * kLdsStageFloats];\n    const unsigned long long nf_w0 = wall_clock64();\n    const int lane = threadIdx.x & 63;\n'),
+        ('            default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;\n        }\n    }\n',
+         '            default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;\n        }\n    }\n'
+         '    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;\n')], []),
+    # K6 sample_fine pricing: no output stores / no merge search / no inverse-cdf search / no double-precision scan
+    'sf_nostore': ('sampling.hip', [('    auto emit = [&](int rank, float z) {\n', '    auto emit = [&](int rank, float z) {\n        if (rank != -12345) return;\n')], []),
+    'sf_nomerge': ('sampling.hip', [('                if (p <= n && (is_c ? (o < v) : (o <= v))) lo = p;\n            }\n', '                if (p == -5 && (is_c ? (o < v) : (o <= v))) lo = p;\n                break;\n            }\n')], []),
+    'sf_noinvert': ('sampling.hip', [('        if (p <= n && (STRICT ? o < v : o <= v)) pos = p;\n    }\n', '        if (p <= n && (STRICT ? o < v : o <= v)) pos = p;\n        break;\n    }\n')], []),
+    'sf_noscan': ('sampling.hip', [('        const double incl = wave_scan_add_f64((double)pdf, lane) + carry;\n', '        const double incl = (double)pdf * (double)(lane + 1) + carry;\n')], []),
     'lds_noheads': ('mlp_lds.hip', [('    return s + __shfl_xor(s, 32, 64);\n}\n\n// SKIP:', '    return w[h];\n}\n\n// SKIP:'),
                                     ('        __builtin_amdgcn_sched_barrier(0);\n    }\n    return', '    }\n    return'),
                                     ('            for (int e = 0; e < 4; ++e) s = fmaf(wv[e], relu_bits(x[t][4 * r4 + e]), s);\n',

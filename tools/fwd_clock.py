@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Shader clock actually held during the exact-f32 forward kernel (needs the NF_FWD_ABLATE=9 build of tools/ablate.py,
+"""Shader clock actually held during the exact-f32 forward kernel (needs `python tools/experiment.py fwd_clock`,
 which makes every workgroup write its clock64 / wall_clock64 deltas over the first outputs)."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
 from nerfail_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, 'nerfail_amd', 'lib', 'libnerfail_hip_NF_FWD_ABLATE_9.so')
+_lib.LIB_PATH = os.path.join(ROOT, 'nerfail_amd', 'lib', 'libnerfail_hip_exp_fwd_clock.so')
 import synth
 from nerfail_amd.run_nerf_helpers import NeRF
 dev = torch.device('cuda:0')
@@ -19,6 +19,7 @@ pts = torch.randn((R, N, 3), device=dev)
 vd = torch.nn.functional.normalize(torch.randn((R, 3), device=dev), dim=-1)
 raw = torch.empty((R, N, 4), device=dev)
 lib = _lib.load()
+lib.nerfail_mlp_fwd_select(1)          # the probe lives in the register-streamed kernel
 for _ in range(3):
     _lib.check(lib.nerfail_mlp_fwd(_lib.dev(m.packed()), m.D, m.W, m._skip(), _lib.dev(pts), _lib.dev(vd), R * N, N, _lib.dev(raw), _lib.stream()))
 torch.cuda.synchronize()

@@ -41,7 +41,7 @@ def timeit(fn, reps=10):
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument('--lib', default=None, help='alternative libnerfail_hip build (tools/ablate_dw.py)')
+    ap.add_argument('--lib', default=None, help='alternative libnerfail_hip build (tools/experiment.py)')
     ap.add_argument('--only', default=None, help='comma-separated kernel names')
     ap.add_argument('--sizes', default='1024x64,1024x192,8192x192')
     args = ap.parse_args()
