@@ -248,22 +248,32 @@ def render_f16x3_bench(dev, steps=2):
 
 def knn_bench(dev, reps=2):
     """8-NN index build of ONE view (create_index_and_dist.py:126-145): 640 000 queries (the view's pts_max) against the
-    1 920 000-point set of 3 base views; synthetic shell points. Exact (d2, index) ordering."""
+    1 920 000-point set of 3 base views. Exact (d2, index) ordering. Two geometries: the synthetic shell points of
+    SURVEY.md section 8d, and the analytic pts_max of a rendered sphere (40 % surface hits, 60 % background pixels on
+    the near plane, far from every set point: the case the coarse-cell pruning exists for)."""
     from nerfail_amd.create_index_and_dist import index_and_dist
-    S = torch.from_numpy(synth.sphere_shell_points(3 * H * W, seed=0)).to(dev)
-    Q = torch.from_numpy(synth.sphere_shell_points(H * W, seed=1).reshape(H, W, 3)).to(dev)
-    out = index_and_dist(Q, S)
-    torch.cuda.synchronize()
-    t = time.time()
-    for _ in range(reps):
-        out = index_and_dist(Q, S)
-    torch.cuda.synchronize()
-    dt = (time.time() - t) / reps
-    pairs = float(H * W) * float(3 * H * W)
-    return {'views_per_sec': 1.0 / dt, 'ms_per_view': dt * 1e3, 'queries_per_sec': H * W / dt,
-            'brute_force_equivalent_pairs_per_sec': pairs / dt,
-            'note': 'brute-force-equivalent pair rate; 8 flops per pair without FMA would be bound by %.1f TFLOP/s vector f32'
-                    % (PEAK_F32_MFMA_TFLOPS / 2)}
+    out = {}
+    geo = {'shell_points': (synth.sphere_shell_points(3 * H * W, seed=0), synth.sphere_shell_points(H * W, seed=1).reshape(H, W, 3)),
+           'rendered_view_geometry': (np.stack([synth.sphere_view_points(H, W, th) for th in (-120., 0., 120.)]).reshape(-1, 3),
+                                      synth.sphere_view_points(H, W, 45.).reshape(H, W, 3))}
+    for name, (S_, Q_) in geo.items():
+        S, Q = torch.from_numpy(np.ascontiguousarray(S_, np.float32)).to(dev), torch.from_numpy(np.ascontiguousarray(Q_, np.float32)).to(dev)
+        index_and_dist(Q, S)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            index_and_dist(Q, S)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) / reps * 1e-3
+        alg = 7.68e6 + 23.04e6 + 40.96e6                   # SURVEY.md section 8d: Q + S + out = 71.7 MB per view
+        out[name] = {'views_per_sec': 1.0 / dt, 'ms_per_view': dt * 1e3, 'queries_per_sec': H * W / dt,
+                     'brute_force_equivalent_pairs_per_sec': float(H * W) * float(3 * H * W) / dt,
+                     'roofline': {'bound': 'hbm', 'achieved': alg / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': alg / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                  'note': 'grid build (count / scan / scatter) + search; the search is latency / VALU bound, not HBM'}}
+    out.update(out['shell_points'])                          # round-1 keys keep their meaning (shell points)
+    return out
 
 
 def victim_cnn(num_classes=8):
@@ -288,7 +298,7 @@ def attack_bench(dev, iters=5):
     from nerfail_amd.attack import igsm_step, nerfail_s_step
     rs = np.random.RandomState(0)
     P, B = 3, 8
-    wi, ori, s_init = _attack_inputs(dev, B, seed=0)          # maps built by K8 + K9 on the synthetic shell point set
+    wi, ori, s_init = _attack_inputs(dev, B, seed=0)          # maps built by K8 + K9 on the analytic view geometry
     G = torch.from_numpy(rs.normal(size=(B, H, W, 4)).astype(np.float32)).to(dev)
     out = {}
 
@@ -313,6 +323,8 @@ def attack_bench(dev, iters=5):
             'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
             'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
+
+    out['gauss_kernels'] = gauss_kernel_rooflines(dev, wi, ori, s_init, G)
 
     torch.manual_seed(0)
     victim = victim_cnn(8).to(dev)
@@ -357,6 +369,52 @@ def attack_bench(dev, iters=5):
                                           'PyTorch) + one multi-RHS pass over the inverted index'}
     out['batch_views'] = B
     out['unit'] = 'NeRFail-S iterations/s (batch of 8 views, 800x800, P=3)'
+    return out
+
+
+def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
+    """K10 / K11 / K12 one by one through the C-ABI, HIP events on the launch stream, each against the HBM roof with its
+    own algorithmic bytes (102.4 MB and 81.9 MB per view, 122.9 MB per K12 step) and the PMC
+    traffic of its kernels (pmc_traffic: only when the stored counters were taken from these very sources)."""
+    from nerfail_amd import _lib
+    from nerfail_amd.GaussNet import view_indices, view_table
+    lib = _lib.load()
+    B, P, Ns = wi.shape[0], H * W, s_init.numel() // 4
+    s = s_init.reshape(-1, 4).contiguous()
+    x, xr = torch.empty_like(ori), torch.empty_like(ori)
+    gs, s_new = torch.empty((Ns, 4), device=dev), torch.empty((Ns, 4), device=dev)
+    vis = view_indices(wi, Ns)                                # the per-view inverted indices (N2; built once, cached)
+    table, floats = view_table(vis)
+    scratch = torch.empty((floats,), device=dev)
+    st = _lib.stream()
+    calls = {
+        'K10_gauss_fwd': (lambda: lib.nerfail_gauss_fwd(_lib.dev(s), Ns, _lib.dev(wi), _lib.dev(ori), B, P, -1.0, _lib.dev(x), _lib.dev(xr), None, st),
+                          B * 102.4e6, ('gauss_fwd_kernel',)),
+        'K11_gauss_bwd_views': (lambda: lib.nerfail_gauss_bwd_views(_lib.dev(ori), _lib.dev(x), None, _lib.dev(G), table, B, Ns, P, -1.0,
+                                                                   _lib.dev(scratch), _lib.dev(gs), st),
+                                B * 81.9e6, ('gauss_pixel_grad_kernel', 'gauss_seg_reduce_views_kernel', 'gauss_seg_combine_views_kernel', 'gauss_rows_sum_kernel')),
+        'K12_igsm_step': (lambda: lib.nerfail_igsm_step(_lib.dev(s), _lib.dev(gs), _lib.dev(s), Ns, 2.0, 32.0, 0, _lib.dev(s_new), st),
+                          122.9e6, ('igsm_step_kernel',)),
+    }
+    out = {}
+    for name, (fn, alg, kernels) in calls.items():
+        for _ in range(2):
+            _lib.check(fn())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            _lib.check(fn())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        traffic, src = 0.0, None
+        for k in kernels:                                     # PMC bytes per launch (every kernel launches once per call)
+            t, src = pmc_traffic(k)
+            traffic = None if (t is None or traffic is None) else traffic + t
+        out[name] = {'ms_per_call': ms, 'kernels': list(kernels), 'algorithmic_bytes_per_call': alg,
+                     'roofline': {'bound': 'hbm', 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': src}}
+    out['inverted_index_bytes_per_view'] = int(sum(vi.nbytes() for vi in vis) / len(vis))
     return out
 
 
@@ -594,7 +652,7 @@ def main():
 
     # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes of this same command (corrected as
     # MI355X_MICROARCH.md prescribes); profiles/ travels with the repo, the counters cannot be read from inside bench.py
-    traffic, traffic_source = pmc_traffic('nerf_mlp_fwd_kernel')
+    traffic, traffic_source = pmc_traffic('nerf_mlp_fwd_lds_kernel')
     comp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in comp_events)
     comp_bytes = sum(b for _, _, b in comp_events)
     mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in mlp_events)

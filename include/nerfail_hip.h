@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NERFAIL_ABI_VERSION 2
+#define NERFAIL_ABI_VERSION 3
 
 #define NERFAIL_OK 0
 #define NERFAIL_EINVAL 1   /* bad argument (null pointer, size, unsupported shape) */
@@ -254,18 +254,33 @@ int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* gra
                           int64_t Ns, int64_t B, int64_t P, float epsilon, float* scratch, int accumulate,
                           float* grad_spatial, void* stream);
 
-/* One view's inverted index (arrays of nerfail_gauss_csr_build with B = 1; contrib holds pixel*8 + k of THAT view). */
+/* Row ordinals of ONE view's index (arrays of nerfail_gauss_csr_build with B = 1): pos[Ns] = ordinal of row j among the
+ * view's non-empty rows, -1 for an empty row; ord_of[e] = pos[row_of[e]] for the first min(entry_capacity, row_ptr[Ns])
+ * entries; n_rows[0] (device) = number of non-empty rows. */
+size_t nerfail_gauss_view_ranks_workspace_bytes(int64_t Ns);
+int nerfail_gauss_view_ranks(const int32_t* row_ptr, const int32_t* row_of, int64_t Ns, int64_t entry_capacity, int32_t* pos,
+                             int32_t* ord_of, int32_t* n_rows, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One view's inverted index: the arrays of nerfail_gauss_csr_build with B = 1 (contrib holds pixel*8 + k of THAT view)
+ * plus the row ordinals of nerfail_gauss_view_ranks. All pointers are device memory; the counts are host values (read
+ * back once when the index is built). */
 typedef struct nerfail_view_index {
-    const int32_t* row_ptr;    /* [Ns+1] */
-    const int32_t* contrib;    /* [>= row_ptr[Ns]] */
-    const float* w_sorted;
-    const int32_t* row_of;
+    const int32_t* row_ptr;    /* [Ns+1]      (not read by nerfail_gauss_bwd_views; the single-index calls use it)      */
+    const int32_t* contrib;    /* [n_entries] */
+    const float* w_sorted;     /* [n_entries] */
+    const int32_t* row_of;     /* [n_entries] (not read by nerfail_gauss_bwd_views; may be NULL there)                  */
+    const int32_t* ord_of;     /* [n_entries] ordinal of the entry's row among the view's non-empty rows                */
+    const int32_t* pos;        /* [Ns]        ordinal of a row, -1 if the view has no entry for it                      */
+    int64_t n_entries;         /* = row_ptr[Ns]: entries with non-zero weight                                           */
+    int64_t n_rows;            /* non-empty rows                                                                        */
 } nerfail_view_index;
 /* The backward of a BATCH of views through their per-view indices (host table of n_views structs): per-pixel gradients of
- * the whole batch in one pass, then one reduction per view, accumulated in view order (fixed: bitwise reproducible).
- * ori_img / x / grad_* are [n_views*P, 4]; grad_spatial [Ns,4] is overwritten. A view's map is static, so its index is
- * built once whatever batches it later appears in (the reference's DataLoader shuffles, AS:222-231).
- * scratch: nerfail_gauss_bwd_scratch_floats(n_views, P, 1) floats. */
+ * the whole batch in one pass; every view's entries reduced to that view's own row sums (all views in one launch, no
+ * shared destination); the views' sums added row by row IN VIEW ORDER. No atomics, every order fixed: bitwise
+ * reproducible. ori_img / x / grad_* are [n_views*P, 4]; grad_spatial [Ns,4] is overwritten. A view's map is static, so
+ * its index is built once whatever batches it later appears in (the reference's DataLoader shuffles, AS:222-231).
+ * scratch: nerfail_gauss_bwd_views_scratch_floats(views, n_views, P) floats (0 = bad arguments). */
+size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_index* views, int n_views, int64_t P);
 int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
                             const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
                             float* scratch, float* grad_spatial, void* stream);

@@ -64,25 +64,49 @@ class ViewIndex:
     shuffles: batch compositions do not repeat) - and can be stored next to index_and_weight/<split>/<i>.pth.
     Arrays are trimmed to the entries that exist (background pixels contribute none: ~40 % of 8*H*W on a real view)."""
 
+    ARRAYS = ('row_ptr', 'contrib', 'w_sorted', 'row_of', 'ord_of', 'pos')
+
     def __init__(self, wi_view=None, Ns=None, state=None):
         if state is not None:
             self.Ns, self.P = int(state['Ns']), int(state['P'])
+            self.n_entries, self.n_rows = int(state['n_entries']), int(state['n_rows'])
             dev = _cuda()
-            self.row_ptr, self.contrib, self.w_sorted, self.row_of = (state[k].to(dev).contiguous() for k in
-                                                                      ('row_ptr', 'contrib', 'w_sorted', 'row_of'))
+            for k in self.ARRAYS:
+                setattr(self, k, state[k].to(dev).contiguous())
             return
+        lib = _lib.load()
         full = GaussCSR(wi_view.unsqueeze(0) if wi_view.dim() == 4 else wi_view, Ns)
-        n = int(full.row_ptr[-1])                      # one host read per view, at build time only
+        dev = full.row_ptr.device
+        # row ordinals (nerfail_gauss_view_ranks): the batched backward reduces every view into its own compact row-sum
+        # array, addressed by ordinal, and adds the views' sums row by row through `pos`
+        self.pos = torch.empty((Ns,), dtype=torch.int32, device=dev)
+        ord_full = torch.empty_like(full.row_of)
+        counts = torch.empty((1,), dtype=torch.int32, device=dev)
+        nb = lib.nerfail_gauss_view_ranks_workspace_bytes(Ns)
+        ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.nerfail_gauss_view_ranks(_lib.dev(full.row_ptr), _lib.dev(full.row_of), Ns, ord_full.numel(), _lib.dev(self.pos),
+                                                _lib.dev(ord_full), _lib.dev(counts), _lib.dev(ws), nb, _lib.stream()))
+        n = int(full.row_ptr[-1])                      # host reads: once per view, at build time only
+        self.n_entries, self.n_rows = n, int(counts[0])
         self.Ns, self.P = Ns, full.P
         self.row_ptr = full.row_ptr
-        self.contrib, self.w_sorted, self.row_of = (t[:max(n, 1)].clone() for t in (full.contrib, full.w_sorted, full.row_of))
+        # trimmed to the entries that exist (kept >= 1 long so that the pointers stay valid for an all-background view)
+        self.contrib, self.w_sorted, self.row_of, self.ord_of = (t[:max(n, 1)].clone() for t in
+                                                                 (full.contrib, full.w_sorted, full.row_of, ord_full))
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in (self.row_ptr, self.contrib, self.w_sorted, self.row_of))
+        return sum(getattr(self, k).numel() * getattr(self, k).element_size() for k in self.ARRAYS)
+
+    def fill(self, st):
+        """Writes this index into a nerfail_view_index struct (the tensors must stay alive while it is used)."""
+        for k in self.ARRAYS:
+            setattr(st, k, getattr(self, k).data_ptr())
+        st.n_entries, st.n_rows = self.n_entries, self.n_rows
 
     def state_dict(self):
-        return {'Ns': self.Ns, 'P': self.P, 'row_ptr': self.row_ptr.cpu(), 'contrib': self.contrib.cpu(),
-                'w_sorted': self.w_sorted.cpu(), 'row_of': self.row_of.cpu()}
+        d = {k: getattr(self, k).cpu() for k in self.ARRAYS}
+        d.update(Ns=self.Ns, P=self.P, n_entries=self.n_entries, n_rows=self.n_rows)
+        return d
 
     def save(self, path):
         torch.save(self.state_dict(), path)
@@ -90,6 +114,14 @@ class ViewIndex:
     @staticmethod
     def load(path):
         return ViewIndex(state=torch.load(path, map_location='cpu'))
+
+
+def view_table(indices):
+    """Host table of nerfail_view_index structs for nerfail_gauss_bwd_views, and the floats of scratch that call needs."""
+    table = (_lib.ViewIndexStruct * len(indices))()
+    for b, vi in enumerate(indices):
+        vi.fill(table[b])
+    return table, _lib.load().nerfail_gauss_bwd_views_scratch_floats(table, len(indices), indices[0].P)
 
 
 _VIEW_CACHE = {}                     # key -> ViewIndex, insertion order = LRU order
@@ -181,15 +213,12 @@ class _GaussGather(torch.autograd.Function):
         gx = _lib.f32c(grad_x) if grad_x is not None else None
         gr = _lib.f32c(grad_x_rgba) if grad_x_rgba is not None else None
         if ctx.deterministic:
-            # one reduction per view over that view's own index, accumulated in view order (fixed order: bitwise
+            # every view reduced over its own index, the views' row sums added in view order (fixed order: bitwise
             # reproducible whatever else is in the cache)
             gs = torch.empty((n, 4), dtype=torch.float32, device=x.device)
-            scratch = torch.empty((lib.nerfail_gauss_bwd_scratch_floats(B, P, 1),), dtype=torch.float32, device=x.device)
             vis = view_indices(wi, n, ctx.view_ids)
-            table = (_lib.ViewIndexStruct * B)()
-            for b, vi in enumerate(vis):
-                table[b].row_ptr, table[b].contrib = vi.row_ptr.data_ptr(), vi.contrib.data_ptr()
-                table[b].w_sorted, table[b].row_of = vi.w_sorted.data_ptr(), vi.row_of.data_ptr()
+            table, floats = view_table(vis)
+            scratch = torch.empty((floats,), dtype=torch.float32, device=x.device)
             _lib.check(lib.nerfail_gauss_bwd_views(_lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr), table, B, n, P,
                                                    ctx.eps, _lib.dev(scratch), _lib.dev(gs), _lib.stream()))
         else:

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: libnerfail_hip.so binds to 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFAIL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerfail_hip.so')   # override: A/B builds (tools/ablate.py)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DEPTH = 16
 RAY_FLOATS = 11
 
@@ -78,6 +78,9 @@ SIGNATURES = {
     'nerfail_gauss_csr_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i64, c_i64]),
     'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_bwd_scratch_floats': (ctypes.c_size_t, [c_i64, c_i64, c_i]),
+    'nerfail_gauss_view_ranks_workspace_bytes': (ctypes.c_size_t, [c_i64]),
+    'nerfail_gauss_view_ranks': (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    'nerfail_gauss_bwd_views_scratch_floats': (ctypes.c_size_t, [c_p, c_i, c_i64]),
     'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
     'nerfail_gauss_bwd_views': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     'nerfail_gauss_bwd_csr_multi': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
@@ -92,7 +95,8 @@ SIGNATURES = {
 
 class ViewIndexStruct(ctypes.Structure):
     """struct nerfail_view_index (include/nerfail_hip.h)"""
-    _fields_ = [('row_ptr', c_p), ('contrib', c_p), ('w_sorted', c_p), ('row_of', c_p)]
+    _fields_ = [('row_ptr', c_p), ('contrib', c_p), ('w_sorted', c_p), ('row_of', c_p), ('ord_of', c_p), ('pos', c_p),
+                ('n_entries', c_i64), ('n_rows', c_i64)]
 
 
 class AdamTensor(ctypes.Structure):

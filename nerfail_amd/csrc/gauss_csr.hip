@@ -109,17 +109,35 @@ constexpr int kSegNone = 0x7fffffff;           // row id of a padding lane / "no
 
 __device__ __forceinline__ float4 f4_add(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+
+// One step of the segmented scan: every lane looks at the lane the DPP control names (a lane without a source - row
+// start, masked row - sees key -2, which no entry has) and adds that lane's sums if it holds the same key.
+template <int CTRL, int ROW_MASK = 0xF, int C>
+__device__ __forceinline__ void seg_scan_step(const int key, float4 (&v)[C]) {
+    const int key_src = __builtin_amdgcn_update_dpp(-2, key, CTRL, ROW_MASK, 0xF, false);
+    const bool same = key_src == key;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float ax = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].x), CTRL, ROW_MASK, 0xF, false));
+        const float ay = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].y), CTRL, ROW_MASK, 0xF, false));
+        const float az = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].z), CTRL, ROW_MASK, 0xF, false));
+        const float aw = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].w), CTRL, ROW_MASK, 0xF, false));
+        if (same) { v[c].x += ax; v[c].y += ay; v[c].z += az; v[c].w += aw; }
+    }
+}
+
+// The work of one wave = one chunk `wg` of an index with E entries. key_of[e] names the destination of entry e (equal
+// for the entries of one row, entries sorted by it): a row id when `out` is the dense table (stride = Ns), a row ORDINAL
+// when `out` is a view's compact row-sum array (stride = its row count; nerfail_gauss_bwd_views).
 template <int C>
-__global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __restrict__ n_entries, const int* __restrict__ row_of,
-                                                               const int* __restrict__ contrib, const float* __restrict__ w_sorted,
-                                                               const float4* __restrict__ g_pix, int accumulate,
-                                                               float4* __restrict__ grad_spatial, long Ns,
-                                                               int* __restrict__ rec_row, float4* __restrict__ rec_val) {
+__device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, const long E, const int* __restrict__ row_of,
+                                                 const int* __restrict__ contrib, const float* __restrict__ w_sorted,
+                                                 const float4* __restrict__ g_pix, const int accumulate,
+                                                 float4* __restrict__ grad_spatial, const long Ns,
+                                                 int* __restrict__ rec_row, float4* __restrict__ rec_val) {
     // UB: steps whose gathers are issued together (register budget: UB * C float4 per lane)
     constexpr int UB = C == 1 ? 8 : (C == 2 ? 4 : (C <= 4 ? 2 : 1));
-    const int lane = threadIdx.x & 63;
-    const long wg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);         // chunk = wave
-    const long E = *n_entries;
     const long base = wg * kSegChunk;
     // record slots of this chunk: [4*wg] head row, [4*wg+1] tail row, [4*wg+2] tail-starts-here flag
     if (lane == 0) { rec_row[4 * wg] = kSegNone; rec_row[4 * wg + 1] = kSegNone; rec_row[4 * wg + 2] = 0; }
@@ -169,19 +187,19 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __rest
             for (int c = 0; c < C; ++c)
                 v[c] = key[u] != kSegNone ? make_float4(w[u] * g[u][c].x, w[u] * g[u][c].y, w[u] * g[u][c].z, w[u] * g[u][c].w)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);   // (keeps 0 * inf of a clamped lane out)
-            // inclusive segmented scan over the 64 lanes (keys are sorted: equal keys are contiguous)
-#pragma unroll
-            for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                const int key_up = __shfl_up(key[u], dlt, 64);          // (every lane takes part: no shuffle under a condition)
-                const bool same = lane >= dlt && key_up == key[u];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float ax = __shfl_up(v[c].x, dlt, 64), ay = __shfl_up(v[c].y, dlt, 64);
-                    const float az = __shfl_up(v[c].z, dlt, 64), aw = __shfl_up(v[c].w, dlt, 64);
-                    if (same) { v[c].x += ax; v[c].y += ay; v[c].z += az; v[c].w += aw; }
-                }
-            }
-            const int key0 = __shfl(key[u], 0, 64);
+            // inclusive segmented scan over the 64 lanes (keys are sorted: equal keys are contiguous), on DPP moves:
+            // Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the last lane of a row handed to the
+            // next row (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) - if that lane's key is mine,
+            // everything between it and me has that key too, so its sum is exactly what my run is missing.
+            // (__shfl_up is ds_bpermute_b32 on gfx9: 36 trips through the CU's LDS crossbar per 64 entries kept this
+            // kernel at 186 us per 8-view batch whatever its HBM traffic was.)
+            seg_scan_step<0x111>(key[u], v);
+            seg_scan_step<0x112>(key[u], v);
+            seg_scan_step<0x114>(key[u], v);
+            seg_scan_step<0x118>(key[u], v);
+            seg_scan_step<0x142, 0xA>(key[u], v);
+            seg_scan_step<0x143, 0xC>(key[u], v);
+            const int key0 = __builtin_amdgcn_readlane(key[u], 0);
             if (key[u] == key0 && key0 == carry_row) {                 // the run carried over from the previous 64 entries
 #pragma unroll
                 for (int c = 0; c < C; ++c) v[c] = f4_add(carry[c], v[c]);
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __rest
                     for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = carry[c];
                 } else emit(carry_row, carry, true);
             }
-            const int key_next = __shfl_down(key[u], 1, 64);
+            const int key_next = __builtin_amdgcn_update_dpp(kSegNone, key[u], 0x130, 0xF, 0xF, false);   // wave_shl:1 = lane + 1
             const bool closed = lane != 63 && key_next != key[u] && key[u] != kSegNone;   // run ends inside these 64 entries
             if (closed) {
                 if (key[u] == first_row && head_partial) {             // began in an earlier chunk: partial (head) record
@@ -203,10 +221,10 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __rest
                     for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = v[c];
                 } else emit(key[u], v, true);
             }
-            carry_row = __shfl(key[u], 63, 64);                        // the run of the last lane stays open
+            carry_row = __builtin_amdgcn_readlane(key[u], 63);         // the run of the last lane stays open
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                carry[c] = make_float4(__shfl(v[c].x, 63, 64), __shfl(v[c].y, 63, 64), __shfl(v[c].z, 63, 64), __shfl(v[c].w, 63, 64));
+                carry[c] = make_float4(lane63(v[c].x), lane63(v[c].y), lane63(v[c].z), lane63(v[c].w));
         }
     }
     if (lane == 0 && carry_row != kSegNone) {                          // the run still open at the end of the chunk
@@ -226,13 +244,61 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __rest
     }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __restrict__ n_entries, const int* __restrict__ row_of,
+                                                               const int* __restrict__ contrib, const float* __restrict__ w_sorted,
+                                                               const float4* __restrict__ g_pix, int accumulate,
+                                                               float4* __restrict__ grad_spatial, long Ns,
+                                                               int* __restrict__ rec_row, float4* __restrict__ rec_val) {
+    seg_reduce_chunk<C>((long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, *n_entries, row_of, contrib, w_sorted, g_pix,
+                        accumulate, grad_spatial, Ns, rec_row, rec_val);
+}
+
+// All views of a batch in ONE launch (blockIdx.y = view): every view reduces its own entries into its own compact
+// row-sum array, so the views do not touch common memory and need no order among them; gauss_rows_sum_kernel then adds
+// the views' sums row by row in view order. (One launch per view, each accumulating into the table, left the chip at
+// ~2 waves per SIMD and serialised 16 launches: 0.37 ms per 8-view batch against 0.1 ms here.)
+constexpr int kViewsPerLaunch = 16;
+struct SegViews {
+    long E[kViewsPerLaunch];                    // entries of the view's index
+    long chunks[kViewsPerLaunch];               // record slots (waves) of the view
+    long n_rows[kViewsPerLaunch];
+    long block_start[kViewsPerLaunch];          // first workgroup of the view in the flat list (reduce kernel)
+    long total_blocks;
+    const int* ord_of[kViewsPerLaunch];
+    const int* contrib[kViewsPerLaunch];
+    const float* w_sorted[kViewsPerLaunch];
+    const float4* g_pix[kViewsPerLaunch];
+    float4* val[kViewsPerLaunch];               // [n_rows] row sums of the view
+    int* rec_row[kViewsPerLaunch];
+    float4* rec_val[kViewsPerLaunch];
+    int nv;
+};
+
+// Workgroup -> (view, chunk quad): the launch is the flat list of all views' chunk quads, cut into 8 contiguous parts,
+// one per XCD (consecutive workgroup ids go round-robin over the 8 XCDs). Each XCD's L2 then serves ONE view's
+// per-pixel gradients (10 MB, swept in step with the rows) instead of all of them at once: with the plain (x = chunk,
+// y = view) grid the 16-byte gathers were re-fetched 3.5 times (729 MB of L2 fills per 8-view batch for 205 MB of
+// algorithmic bytes, rocprofv3 FETCH_SIZE) and the kernel ran at the fabric's rate.
+__global__ __launch_bounds__(256) void gauss_seg_reduce_views_kernel(SegViews a) {
+    const long per_xcd = (a.total_blocks + 7) >> 3;
+    long vb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((long)(blockIdx.x >> 3) >= per_xcd || vb >= a.total_blocks) return;
+    int v = 0;
+#pragma unroll
+    for (int i = 1; i < kViewsPerLaunch; ++i)
+        if (i < a.nv && vb >= a.block_start[i]) v = i;                 // block_start ascends
+    const long wg = (vb - a.block_start[v]) * 4 + (threadIdx.x >> 6);
+    if (wg >= a.chunks[v]) return;                                     // wave-uniform
+    seg_reduce_chunk<1>(wg, threadIdx.x & 63, a.E[v], a.ord_of[v], a.contrib[v], a.w_sorted[v], a.g_pix[v], 0, a.val[v],
+                        a.n_rows[v], a.rec_row[v], a.rec_val[v]);
+}
+
 // Rows that cross chunk boundaries: the chunk where such a row starts adds up its partial records in chunk order.
 template <int C>
-__global__ __launch_bounds__(256) void gauss_seg_combine_kernel(const int* __restrict__ rec_row, const float4* __restrict__ rec_val,
-                                                                long chunks, int accumulate, float4* __restrict__ grad_spatial,
-                                                                long Ns) {
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= chunks) return;
+__device__ __forceinline__ void seg_combine_chunk(const long k, const int* __restrict__ rec_row, const float4* __restrict__ rec_val,
+                                                  const long chunks, const int accumulate, float4* __restrict__ grad_spatial,
+                                                  const long Ns) {
     const int row = rec_row[4 * k + 1];
     if (row == kSegNone || rec_row[4 * k + 2] == 0) return;            // no open row here, or it did not start here
     float4 s[C];
@@ -254,6 +320,68 @@ __global__ __launch_bounds__(256) void gauss_seg_combine_kernel(const int* __res
         if (accumulate) o = f4_add(grad_spatial[(long)c * Ns + row], o);
         grad_spatial[(long)c * Ns + row] = o;
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void gauss_seg_combine_kernel(const int* __restrict__ rec_row, const float4* __restrict__ rec_val,
+                                                                long chunks, int accumulate, float4* __restrict__ grad_spatial,
+                                                                long Ns) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= chunks) return;
+    seg_combine_chunk<C>(k, rec_row, rec_val, chunks, accumulate, grad_spatial, Ns);
+}
+
+__global__ __launch_bounds__(256) void gauss_seg_combine_views_kernel(SegViews a) {
+    const int v = blockIdx.y;
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.chunks[v]) return;
+    seg_combine_chunk<1>(k, a.rec_row[v], a.rec_val[v], a.chunks[v], 0, a.val[v], a.n_rows[v]);
+}
+
+// grad_spatial[j] = (accumulate ? grad_spatial[j] : 0) + sum over the views, IN VIEW ORDER, of the view's sum for row j
+// (pos[v][j] = the row's ordinal in view v's compact array, -1 = the view has no entry for it). Ordinals ascend with j,
+// so a wave's reads of a view's sums are one nearly contiguous run.
+struct RowsSum {
+    const int* pos[kViewsPerLaunch];
+    const float4* val[kViewsPerLaunch];
+    int nv;
+};
+
+__global__ __launch_bounds__(256) void gauss_rows_sum_kernel(RowsSum a, long Ns, int accumulate, float4* __restrict__ grad_spatial) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ns) return;
+    int p[kViewsPerLaunch];
+#pragma unroll
+    for (int v = 0; v < kViewsPerLaunch; ++v) p[v] = v < a.nv ? a.pos[v][j] : -1;      // all index loads first
+    float4 s = accumulate ? grad_spatial[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int v = 0; v < kViewsPerLaunch; ++v)
+        if (p[v] >= 0) s = f4_add(s, a.val[v][p[v]]);
+    grad_spatial[j] = s;
+}
+
+// Row ordinals of a view index: pos[j] = number of non-empty rows before row j, or -1 for an empty row; ord_of[e] =
+// pos[row of entry e]; n_rows = number of non-empty rows. (flags -> exclusive sum -> fix-up)
+__global__ __launch_bounds__(256) void view_row_flags_kernel(const int* __restrict__ row_ptr, long Ns, int* __restrict__ flags) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < Ns) flags[j] = row_ptr[j + 1] > row_ptr[j] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void view_row_pos_kernel(const int* __restrict__ row_ptr, long Ns, int* __restrict__ pos,
+                                                           int* __restrict__ n_rows) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ns) return;
+    const bool any = row_ptr[j + 1] > row_ptr[j];
+    const int before = pos[j];                                  // the exclusive sum of the flags
+    if (j == Ns - 1) *n_rows = before + (any ? 1 : 0);
+    pos[j] = any ? before : -1;
+}
+
+__global__ __launch_bounds__(256) void view_entry_ord_kernel(const int* __restrict__ row_ptr, long Ns, const int* __restrict__ row_of,
+                                                             const int* __restrict__ pos, long cap, int* __restrict__ ord_of) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cap || e >= row_ptr[Ns]) return;
+    ord_of[e] = pos[row_of[e]];
 }
 
 // ---- multi-RHS form (DeepFool: the gradients of all class logits of one iteration, deepfool.py:66-96). The index
@@ -424,37 +552,101 @@ extern "C" int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const
     return run_seg_reduce<1>(row_ptr, contrib, w_sorted, row_of, Ns, B, P, scratch, accumulate, grad_spatial, s);
 }
 
+static long view_chunks(long n_entries) { return ((n_entries + kSegChunk - 1) / kSegChunk + 3) / 4 * 4; }
+
+extern "C" size_t nerfail_gauss_view_ranks_workspace_bytes(int64_t Ns) {
+    if (Ns <= 0 || Ns >= (1L << 31) - 1) return 0;
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (int)Ns, (hipStream_t) nullptr);
+    return align256((size_t)Ns * 4) + align256(bytes);
+}
+
+extern "C" int nerfail_gauss_view_ranks(const int32_t* row_ptr, const int32_t* row_of, int64_t Ns, int64_t entry_capacity,
+                                        int32_t* pos, int32_t* ord_of, int32_t* n_rows, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    NF_REQUIRE(Ns > 0 && Ns < (1L << 31) - 1 && entry_capacity >= 0, "bad sizes");
+    NF_REQUIRE(row_ptr && row_of && pos && ord_of && n_rows && workspace, "NULL pointer");
+    NF_REQUIRE(workspace_bytes >= nerfail_gauss_view_ranks_workspace_bytes(Ns), "workspace too small (nerfail_gauss_view_ranks_workspace_bytes)");
+    hipStream_t s = as_stream(stream);
+    int* flags = (int*)workspace;
+    void* temp = (char*)workspace + align256((size_t)Ns * 4);
+    size_t temp_bytes = workspace_bytes - align256((size_t)Ns * 4);
+    const unsigned gb = (unsigned)((Ns + 255) / 256);
+    view_row_flags_kernel<<<dim3(gb), dim3(256), 0, s>>>(row_ptr, Ns, flags);
+    NF_LAUNCHED("view_row_flags_kernel");
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, flags, pos, (int)Ns, s);
+    if (e != hipSuccess) return hip_fail(e, "hipcub::DeviceScan::ExclusiveSum");
+    view_row_pos_kernel<<<dim3(gb), dim3(256), 0, s>>>(row_ptr, Ns, pos, n_rows);
+    NF_LAUNCHED("view_row_pos_kernel");
+    if (entry_capacity > 0) {
+        view_entry_ord_kernel<<<dim3((unsigned)((entry_capacity + 255) / 256)), dim3(256), 0, s>>>(row_ptr, Ns, row_of, pos,
+                                                                                                  entry_capacity, ord_of);
+        NF_LAUNCHED("view_entry_ord_kernel");
+    }
+    return NERFAIL_OK;
+}
+
+static bool view_ok(const nerfail_view_index& v, long Ns, long P) {
+    return v.contrib && v.w_sorted && v.ord_of && v.pos && v.n_entries >= 0 && v.n_entries <= 8 * P && v.n_rows >= 0 &&
+           v.n_rows <= v.n_entries && v.n_rows <= Ns && (v.n_entries == 0) == (v.n_rows == 0);
+}
+
+extern "C" size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_index* views, int n_views, int64_t P) {
+    if (views == nullptr || n_views < 1 || P <= 0) return 0;
+    size_t f = (size_t)n_views * P * 4;                                 // per-pixel gradients of the batch
+    for (int v = 0; v < n_views; ++v) {
+        if (views[v].n_entries < 0 || views[v].n_rows < 0) return 0;
+        const size_t chunks = (size_t)view_chunks(views[v].n_entries);
+        f += chunks * 2 * 4 + chunks * 4 + (size_t)views[v].n_rows * 4;   // record values, record rows, the view's row sums
+    }
+    return f;
+}
+
 extern "C" int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
                                        const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
                                        float* scratch, float* grad_spatial, void* stream) {
     NF_REQUIRE(Ns > 0 && P > 0 && n_views >= 1, "bad sizes");
     NF_REQUIRE(ori_img && x && views && scratch && grad_spatial, "NULL pointer");
     for (int v = 0; v < n_views; ++v)
-        NF_REQUIRE(views[v].row_ptr && views[v].contrib && views[v].w_sorted && views[v].row_of, "NULL pointer in a view index");
+        NF_REQUIRE(view_ok(views[v], Ns, P), "a view index is incomplete or inconsistent (NULL array, n_entries > 8 P, n_rows > n_entries)");
     hipStream_t s = as_stream(stream);
     const long n = (long)n_views * P;
-    // per-pixel gradients of the whole batch in one launch, then one reduction per view over its own index, in view order
+    // 1. per-pixel gradients of the whole batch in one launch
     gauss_pixel_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
         (const float4*)ori_img, (const float4*)x, (const float4*)grad_x, (const float4*)grad_x_rgba, n, epsilon,
         (float4*)scratch);
     NF_LAUNCHED("gauss_pixel_grad_kernel");
-    float* rec = scratch + (size_t)n * 4;                              // record area behind the batch's pixel gradients
-    for (int v = 0; v < n_views; ++v) {
-        const long chunks = ((seg_chunks(1, P) + 3) / 4) * 4;
-        const float4* g_pix = (const float4*)scratch + (size_t)v * P;
-        float4* rec_val = (float4*)rec;
-        int* rec_row = (int*)(rec_val + (size_t)2 * chunks);
-        if (v == 0) {
-            hipError_t e = hipMemsetAsync(grad_spatial, 0, (size_t)Ns * 16, s);
-            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
+    // 2. every view's entries -> its own row sums (one launch for up to 16 views); 3. the views' sums added per row
+    float* cursor = scratch + (size_t)n * 4;
+    for (int v0 = 0; v0 < n_views; v0 += kViewsPerLaunch) {
+        SegViews a;
+        RowsSum r;
+        const int nv = n_views - v0 < kViewsPerLaunch ? n_views - v0 : kViewsPerLaunch;
+        a.nv = r.nv = nv;
+        long max_chunks = 0;
+        for (int i = 0; i < kViewsPerLaunch; ++i) {
+            const nerfail_view_index& vi = views[v0 + (i < nv ? i : 0)];     // (unused slots repeat slot 0: valid pointers)
+            const long chunks = i < nv ? view_chunks(vi.n_entries) : 0;
+            a.E[i] = vi.n_entries; a.chunks[i] = chunks; a.n_rows[i] = vi.n_rows;
+            a.ord_of[i] = vi.ord_of; a.contrib[i] = vi.contrib; a.w_sorted[i] = vi.w_sorted;
+            a.g_pix[i] = (const float4*)scratch + (size_t)(v0 + (i < nv ? i : 0)) * P;
+            a.rec_val[i] = (float4*)cursor;
+            a.rec_row[i] = (int*)(cursor + (size_t)chunks * 8);
+            a.val[i] = (float4*)(cursor + (size_t)chunks * 12);
+            r.pos[i] = vi.pos; r.val[i] = a.val[i];
+            if (i < nv) cursor += (size_t)chunks * 12 + (size_t)vi.n_rows * 4;
+            if (chunks > max_chunks) max_chunks = chunks;
         }
-        gauss_seg_reduce_kernel<1><<<dim3((unsigned)(chunks / 4)), dim3(256), 0, s>>>(
-            views[v].row_ptr + Ns, views[v].row_of, views[v].contrib, views[v].w_sorted, g_pix, 1, (float4*)grad_spatial, Ns,
-            rec_row, rec_val);
-        NF_LAUNCHED("gauss_seg_reduce_kernel");
-        gauss_seg_combine_kernel<1><<<dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s>>>(
-            rec_row, rec_val, chunks, 1, (float4*)grad_spatial, Ns);
-        NF_LAUNCHED("gauss_seg_combine_kernel");
+        a.total_blocks = 0;
+        for (int i = 0; i < kViewsPerLaunch; ++i) { a.block_start[i] = a.total_blocks; a.total_blocks += a.chunks[i] / 4; }
+        if (max_chunks > 0) {
+            gauss_seg_reduce_views_kernel<<<dim3((unsigned)(((a.total_blocks + 7) / 8) * 8)), dim3(256), 0, s>>>(a);
+            NF_LAUNCHED("gauss_seg_reduce_views_kernel");
+            gauss_seg_combine_views_kernel<<<dim3((unsigned)((max_chunks + 255) / 256), (unsigned)nv), dim3(256), 0, s>>>(a);
+            NF_LAUNCHED("gauss_seg_combine_views_kernel");
+        }
+        gauss_rows_sum_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, (float4*)grad_spatial);
+        NF_LAUNCHED("gauss_rows_sum_kernel");
     }
     return NERFAIL_OK;
 }

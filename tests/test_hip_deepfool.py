@@ -146,7 +146,7 @@ def test_deepfool_class_counts_outside_the_multi_rhs_range():
     rs = np.random.RandomState(3)
     w = T((rs.normal(size=(10, 48)) * 0.05).astype(np.float32))
     bias = torch.zeros(10, device=dev())
-    bias[9] = 50.0                                              # prediction = class 9 >= num_classes = 8
+    bias[9] = 1e4                                               # prediction = class 9 >= num_classes = 8 (logits are ~1e2)
 
     class Cls(torch.nn.Module):
         def forward(self, x):
