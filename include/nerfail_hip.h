@@ -254,24 +254,26 @@ int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const float* gra
                           int64_t Ns, int64_t B, int64_t P, float epsilon, float* scratch, int accumulate,
                           float* grad_spatial, void* stream);
 
-/* Row ordinals of ONE view's index (arrays of nerfail_gauss_csr_build with B = 1): pos[Ns] = ordinal of row j among the
- * view's non-empty rows, -1 for an empty row; ord_of[e] = pos[row_of[e]] for the first min(entry_capacity, row_ptr[Ns])
- * entries; n_rows[0] (device) = number of non-empty rows. */
-size_t nerfail_gauss_view_ranks_workspace_bytes(int64_t Ns);
-int nerfail_gauss_view_ranks(const int32_t* row_ptr, const int32_t* row_of, int64_t Ns, int64_t entry_capacity, int32_t* pos,
-                             int32_t* ord_of, int32_t* n_rows, void* workspace, size_t workspace_bytes, void* stream);
+/* The compact form of ONE view's index, from the arrays of nerfail_gauss_csr_build with B = 1:
+ *   pos[Ns]            ordinal of row j among the view's non-empty rows, -1 for an empty row;
+ *   packed[e]          pixel * 2 + (1 if entry e starts a row), for the first min(entry_capacity, row_ptr[Ns]) entries;
+ *   chunk_ord[c]       ordinal of the row of entry 512 c (one int per 512 entries: nerfail_gauss_view_chunks(n) ints);
+ *   n_rows[0] (device) number of non-empty rows.
+ * With w_sorted that is everything the backward reads: 8 bytes per entry + 4 Ns. */
+size_t nerfail_gauss_view_pack_workspace_bytes(int64_t Ns);
+int64_t nerfail_gauss_view_chunks(int64_t n_entries);
+int nerfail_gauss_view_pack(const int32_t* row_ptr, const int32_t* row_of, const int32_t* contrib, int64_t Ns,
+                            int64_t entry_capacity, int32_t* pos, int32_t* packed, int32_t* chunk_ord, int32_t* n_rows,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
-/* One view's inverted index: the arrays of nerfail_gauss_csr_build with B = 1 (contrib holds pixel*8 + k of THAT view)
- * plus the row ordinals of nerfail_gauss_view_ranks. All pointers are device memory; the counts are host values (read
- * back once when the index is built). */
+/* One view's inverted index in compact form (nerfail_gauss_view_pack). All pointers are device memory; the counts are
+ * host values (read back once when the index is built). */
 typedef struct nerfail_view_index {
-    const int32_t* row_ptr;    /* [Ns+1]      (not read by nerfail_gauss_bwd_views; the single-index calls use it)      */
-    const int32_t* contrib;    /* [n_entries] */
-    const float* w_sorted;     /* [n_entries] */
-    const int32_t* row_of;     /* [n_entries] (not read by nerfail_gauss_bwd_views; may be NULL there)                  */
-    const int32_t* ord_of;     /* [n_entries] ordinal of the entry's row among the view's non-empty rows                */
+    const int32_t* packed;     /* [n_entries] pixel * 2 + row-start flag, entries sorted by destination row             */
+    const float* w_sorted;     /* [n_entries] the entry's Gaussian weight                                               */
+    const int32_t* chunk_ord;  /* [nerfail_gauss_view_chunks(n_entries)] row ordinal of every 512th entry               */
     const int32_t* pos;        /* [Ns]        ordinal of a row, -1 if the view has no entry for it                      */
-    int64_t n_entries;         /* = row_ptr[Ns]: entries with non-zero weight                                           */
+    int64_t n_entries;         /* entries with non-zero weight (= row_ptr[Ns] of the csr build)                         */
     int64_t n_rows;            /* non-empty rows                                                                        */
 } nerfail_view_index;
 /* The backward of a BATCH of views through their per-view indices (host table of n_views structs): per-pixel gradients of
@@ -279,11 +281,18 @@ typedef struct nerfail_view_index {
  * shared destination); the views' sums added row by row IN VIEW ORDER. No atomics, every order fixed: bitwise
  * reproducible. ori_img / x / grad_* are [n_views*P, 4]; grad_spatial [Ns,4] is overwritten. A view's map is static, so
  * its index is built once whatever batches it later appears in (the reference's DataLoader shuffles, AS:222-231).
- * scratch: nerfail_gauss_bwd_views_scratch_floats(views, n_views, P) floats (0 = bad arguments). */
-size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_index* views, int n_views, int64_t P);
+ * scratch: nerfail_gauss_bwd_views_scratch_floats(views, n_views, P, 1) floats (0 = bad arguments). */
+size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_index* views, int n_views, int64_t P, int n_rhs);
 int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
                             const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
                             float* scratch, float* grad_spatial, void* stream);
+/* ONE view, n_rhs (1..8) upstream gradients at once - the class-logit gradients of one DeepFool iteration (deepfool.py:
+ * 66-96 takes them one autograd.grad call at a time). grad_x_rgba: [n_rhs][P,4]; grad_spatial: [n_rhs][Ns,4],
+ * overwritten. Sums run in the same order as nerfail_gauss_bwd_views, so each right-hand side gets bitwise the result of
+ * a single call. scratch: nerfail_gauss_bwd_views_scratch_floats(view, 1, P, n_rhs) floats. */
+int nerfail_gauss_bwd_view_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,
+                                 const nerfail_view_index* view, int64_t Ns, int64_t P, float epsilon, float* scratch,
+                                 float* grad_spatial, void* stream);
 
 /* The same backward for n_rhs (1..8) upstream gradients at once - the class-logit gradients of one DeepFool iteration
  * (deepfool.py:66-96 takes them one autograd.grad call at a time). grad_x_rgba: [n_rhs][B*P,4]; grad_spatial:

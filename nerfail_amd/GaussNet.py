@@ -5,6 +5,7 @@ sum, alpha, epsilon clip, composite onto the image) is one HIP kernel with a han
 (scatter-add with float atomics); the cold tail (GN:121-157: layout change, white background, Resize,
 classifier) stays stock PyTorch, as SURVEY.md section 8(a16) scopes it.
 """
+import ctypes
 import weakref
 
 import torch
@@ -64,7 +65,7 @@ class ViewIndex:
     shuffles: batch compositions do not repeat) - and can be stored next to index_and_weight/<split>/<i>.pth.
     Arrays are trimmed to the entries that exist (background pixels contribute none: ~40 % of 8*H*W on a real view)."""
 
-    ARRAYS = ('row_ptr', 'contrib', 'w_sorted', 'row_of', 'ord_of', 'pos')
+    ARRAYS = ('packed', 'w_sorted', 'chunk_ord', 'pos')
 
     def __init__(self, wi_view=None, Ns=None, state=None):
         if state is not None:
@@ -75,24 +76,26 @@ class ViewIndex:
                 setattr(self, k, state[k].to(dev).contiguous())
             return
         lib = _lib.load()
-        full = GaussCSR(wi_view.unsqueeze(0) if wi_view.dim() == 4 else wi_view, Ns)
+        full = GaussCSR(wi_view.unsqueeze(0) if wi_view.dim() == 4 else wi_view, Ns)     # sorted entries (B = 1), temporary
         dev = full.row_ptr.device
-        # row ordinals (nerfail_gauss_view_ranks): the batched backward reduces every view into its own compact row-sum
-        # array, addressed by ordinal, and adds the views' sums row by row through `pos`
+        cap = full.contrib.numel()
+        # compact form (nerfail_gauss_view_pack): 8 bytes per entry (pixel * 2 + row-start flag, weight), one row ordinal
+        # per 512 entries, and pos[Ns] (row -> ordinal in the view's compact row-sum array, -1 = no entry)
         self.pos = torch.empty((Ns,), dtype=torch.int32, device=dev)
-        ord_full = torch.empty_like(full.row_of)
+        packed = torch.empty((cap,), dtype=torch.int32, device=dev)
+        chunk_ord = torch.zeros((int(lib.nerfail_gauss_view_chunks(cap)),), dtype=torch.int32, device=dev)
         counts = torch.empty((1,), dtype=torch.int32, device=dev)
-        nb = lib.nerfail_gauss_view_ranks_workspace_bytes(Ns)
+        nb = lib.nerfail_gauss_view_pack_workspace_bytes(Ns)
         ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
-        _lib.check(lib.nerfail_gauss_view_ranks(_lib.dev(full.row_ptr), _lib.dev(full.row_of), Ns, ord_full.numel(), _lib.dev(self.pos),
-                                                _lib.dev(ord_full), _lib.dev(counts), _lib.dev(ws), nb, _lib.stream()))
+        _lib.check(lib.nerfail_gauss_view_pack(_lib.dev(full.row_ptr), _lib.dev(full.row_of), _lib.dev(full.contrib), Ns, cap,
+                                               _lib.dev(self.pos), _lib.dev(packed), _lib.dev(chunk_ord), _lib.dev(counts),
+                                               _lib.dev(ws), nb, _lib.stream()))
         n = int(full.row_ptr[-1])                      # host reads: once per view, at build time only
         self.n_entries, self.n_rows = n, int(counts[0])
         self.Ns, self.P = Ns, full.P
-        self.row_ptr = full.row_ptr
         # trimmed to the entries that exist (kept >= 1 long so that the pointers stay valid for an all-background view)
-        self.contrib, self.w_sorted, self.row_of, self.ord_of = (t[:max(n, 1)].clone() for t in
-                                                                 (full.contrib, full.w_sorted, full.row_of, ord_full))
+        self.packed, self.w_sorted = packed[:max(n, 1)].clone(), full.w_sorted[:max(n, 1)].clone()
+        self.chunk_ord = chunk_ord[:max(int(lib.nerfail_gauss_view_chunks(n)), 1)].clone()
 
     def nbytes(self):
         return sum(getattr(self, k).numel() * getattr(self, k).element_size() for k in self.ARRAYS)
@@ -121,7 +124,7 @@ def view_table(indices):
     table = (_lib.ViewIndexStruct * len(indices))()
     for b, vi in enumerate(indices):
         vi.fill(table[b])
-    return table, _lib.load().nerfail_gauss_bwd_views_scratch_floats(table, len(indices), indices[0].P)
+    return table, _lib.load().nerfail_gauss_bwd_views_scratch_floats(table, len(indices), indices[0].P, 1)
 
 
 _VIEW_CACHE = {}                     # key -> ViewIndex, insertion order = LRU order
@@ -356,7 +359,7 @@ class gauss_net(nn.Module):
 
         `x, x_rgba, cla` are what forward() just returned for this spatial_rgb (graph still alive). The classifier is
         differentiated down to x_rgba by stock PyTorch (one backward per class); the pixel<->3-D map - the part the reference pays len(classes) scatter passes for - is one
-        nerfail_gauss_bwd_csr_multi launch. Each slice is bitwise what autograd through forward() returns."""
+        nerfail_gauss_bwd_view_multi call. Each slice is bitwise what autograd through forward() returns."""
         if cla.shape[0] != 1:
             raise ValueError('logit_gradients differentiates one view at a time (deepfool runs at batch 1, AN:82)')
         classes = [int(k) for k in classes]
@@ -375,17 +378,18 @@ class gauss_net(nn.Module):
         wi = weight_and_index_list
         B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
         n = spatial_rgb.numel() // 4
-        csr = view_indices(wi, n, getattr(self, '_last_view_ids', None))[0]     # one view (batch 1): its per-view index
+        vi = view_indices(wi, n, getattr(self, '_last_view_ids', None))[0]      # one view (batch 1): its per-view index
         J = _lib.f32c(J).reshape(C, B * P, 4)
         ori = _lib.f32c(self._last_ori)
         out = torch.empty((C, n, 4), dtype=torch.float32, device=J.device)
-        scratch = torch.empty((_lib.load().nerfail_gauss_bwd_scratch_floats(B, P, C),), dtype=torch.float32, device=J.device)
+        lib = _lib.load()
+        st = _lib.ViewIndexStruct()
+        vi.fill(st)
+        scratch = torch.empty((lib.nerfail_gauss_bwd_views_scratch_floats(ctypes.byref(st), 1, P, C),), dtype=torch.float32, device=J.device)
         eps = -1.0 if self.epsilon is None else float(self.epsilon)
         x_c = _lib.f32c(x)            # bound to a name: see deepfool.py on pointers of temporaries
-        _lib.check(_lib.load().nerfail_gauss_bwd_csr_multi(_lib.dev(ori), _lib.dev(x_c), _lib.dev(J), C,
-                                                           _lib.dev(csr.row_ptr), _lib.dev(csr.contrib), _lib.dev(csr.w_sorted),
-                                                           _lib.dev(csr.row_of), n, B, P, eps, _lib.dev(scratch), _lib.dev(out),
-                                                           _lib.stream()))
+        _lib.check(lib.nerfail_gauss_bwd_view_multi(_lib.dev(ori), _lib.dev(x_c), _lib.dev(J), C, ctypes.byref(st), n, P, eps,
+                                                    _lib.dev(scratch), _lib.dev(out), _lib.stream()))
         return out.reshape((C,) + tuple(spatial_rgb.shape))
 
 

@@ -78,9 +78,11 @@ SIGNATURES = {
     'nerfail_gauss_csr_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i64, c_i64]),
     'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_bwd_scratch_floats': (ctypes.c_size_t, [c_i64, c_i64, c_i]),
-    'nerfail_gauss_view_ranks_workspace_bytes': (ctypes.c_size_t, [c_i64]),
-    'nerfail_gauss_view_ranks': (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
-    'nerfail_gauss_bwd_views_scratch_floats': (ctypes.c_size_t, [c_p, c_i, c_i64]),
+    'nerfail_gauss_view_pack_workspace_bytes': (ctypes.c_size_t, [c_i64]),
+    'nerfail_gauss_view_chunks': (c_i64, [c_i64]),
+    'nerfail_gauss_view_pack': (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    'nerfail_gauss_bwd_view_multi': (c_i, [c_p, c_p, c_p, c_i, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p]),
+    'nerfail_gauss_bwd_views_scratch_floats': (ctypes.c_size_t, [c_p, c_i, c_i64, c_i]),
     'nerfail_gauss_bwd_csr': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_i, c_p, c_p]),
     'nerfail_gauss_bwd_views': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     'nerfail_gauss_bwd_csr_multi': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
@@ -95,8 +97,7 @@ SIGNATURES = {
 
 class ViewIndexStruct(ctypes.Structure):
     """struct nerfail_view_index (include/nerfail_hip.h)"""
-    _fields_ = [('row_ptr', c_p), ('contrib', c_p), ('w_sorted', c_p), ('row_of', c_p), ('ord_of', c_p), ('pos', c_p),
-                ('n_entries', c_i64), ('n_rows', c_i64)]
+    _fields_ = [('packed', c_p), ('w_sorted', c_p), ('chunk_ord', c_p), ('pos', c_p), ('n_entries', c_i64), ('n_rows', c_i64)]
 
 
 class AdamTensor(ctypes.Structure):

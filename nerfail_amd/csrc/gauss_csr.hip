@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __r
                                                                float4* __restrict__ g_out) {
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    const float4 x = x_saved[g];
     const float4 o = ori[g];
     float4 gx = (grad_x != nullptr) ? grad_x[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (grad_x_rgba != nullptr && o.w > 0.f) {
+    if (grad_x_rgba != nullptr && o.w > 0.f) {                 // (transparent pixels - most of a view - read nothing else)
+        const float4 x = x_saved[g];
         const float4 gr = grad_x_rgba[g];
         const float alpha = x.w / 255.0f;
         const float xc[3] = {x.x, x.y, x.z}, oc[3] = {o.x, o.y, o.z}, grc[3] = {gr.x, gr.y, gr.z};
@@ -130,7 +130,11 @@ __device__ __forceinline__ void seg_scan_step(const int key, float4 (&v)[C]) {
 // The work of one wave = one chunk `wg` of an index with E entries. key_of[e] names the destination of entry e (equal
 // for the entries of one row, entries sorted by it): a row id when `out` is the dense table (stride = Ns), a row ORDINAL
 // when `out` is a view's compact row-sum array (stride = its row count; nerfail_gauss_bwd_views).
-template <int C>
+// PACKED = a per-view index in its compact form (nerfail_gauss_view_pack): `contrib` holds pixel * 2 + (1 if the entry
+// starts a row), `row_of` holds ONE int per chunk (the ordinal of the row the chunk's first entry belongs to), and an
+// entry's key - its row's ordinal - is that plus the number of row starts up to the entry (a ballot and a bit count per
+// 64 entries): 8 bytes per entry instead of 12.
+template <int C, bool PACKED>
 __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, const long E, const int* __restrict__ row_of,
                                                  const int* __restrict__ contrib, const float* __restrict__ w_sorted,
                                                  const float4* __restrict__ g_pix, const int accumulate,
@@ -143,10 +147,19 @@ __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, 
     if (lane == 0) { rec_row[4 * wg] = kSegNone; rec_row[4 * wg + 1] = kSegNone; rec_row[4 * wg + 2] = 0; }
     if (base >= E) return;                                             // wave-uniform
     const long end = base + kSegChunk < E ? base + kSegChunk : E;
-    const int prev_row = base > 0 ? row_of[base - 1] : -1;
-    const int next_row = end < E ? row_of[end] : -1;
-    const int first_row = row_of[base];
-    const bool head_partial = first_row == prev_row;                   // the chunk's first row began in an earlier chunk
+    int first_row;
+    bool head_partial;                                                 // the chunk's first row began in an earlier chunk
+    bool tail_complete;                                                // the row of the chunk's last entry ends with it
+    if constexpr (PACKED) {
+        first_row = row_of[wg];
+        head_partial = base > 0 && (contrib[base] & 1) == 0;
+        tail_complete = end >= E || (contrib[end] & 1) != 0;
+    } else {
+        first_row = row_of[base];
+        head_partial = base > 0 && row_of[base - 1] == first_row;
+        tail_complete = end >= E || row_of[end] != row_of[end - 1];
+    }
+    int running = first_row;                                           // PACKED: key of the last entry handled so far
     int carry_row = kSegNone;
     float4 carry[C];
 #pragma unroll
@@ -165,23 +178,44 @@ __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, 
 #pragma unroll 1
     for (int u0 = 0; u0 < kSegU; u0 += UB) {
         if (base + (long)u0 * 64 >= end) break;                        // wave-uniform
-        int key[UB];
+        int key[UB], id[UB];
         float w[UB];
         float4 g[UB][C];
+        // all index loads of the batch first, then all gathers: UB * C independent 16-byte gathers in flight. (Left to
+        // itself the compiler interleaves "load contrib[u]; s_waitcnt vmcnt(0); gather" per u - 2 * UB memory round
+        // trips in a chain, each wait also draining the gather before it; the sched_barriers pin the two phases.)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {                                 // all loads of the batch first (clamped: unconditional)
+        for (int u = 0; u < UB; ++u) {                                 // (clamped: unconditional loads)
             const long i = base + (long)(u0 + u) * 64 + lane;
-            const bool ok = i < end;
-            const long ic = ok ? i : end - 1;
-            const int id = contrib[ic];
-            key[u] = ok ? row_of[ic] : kSegNone;
-            w[u] = ok ? w_sorted[ic] : 0.f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id >> 3) * C + c];
+            const long ic = i < end ? i : end - 1;
+            id[u] = contrib[ic];
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
+            const long i = base + (long)(u0 + u) * 64 + lane;
+            const bool ok = i < end;
+            const long ic = ok ? i : end - 1;
+            if constexpr (PACKED) key[u] = ok ? 0 : kSegNone;          // (the ordinal is counted below, step by step)
+            else key[u] = ok ? row_of[ic] : kSegNone;
+            w[u] = ok ? w_sorted[ic] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> (PACKED ? 1 : 3)) * C + c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
             if (base + (long)(u0 + u) * 64 >= end) break;              // wave-uniform
+            if constexpr (PACKED) {
+                // row starts among these 64 entries (the chunk's very first entry does not count: first_row is ITS row)
+                const bool st = key[u] != kSegNone && (id[u] & 1) != 0 && !(u0 + u == 0 && lane == 0);
+                const unsigned long long m = __ballot(st);
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (key[u] != kSegNone) key[u] = running + below + (st ? 1 : 0);
+                running += __popcll(m);
+            }
             float4 v[C];
 #pragma unroll
             for (int c = 0; c < C; ++c)
@@ -228,7 +262,7 @@ __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, 
         }
     }
     if (lane == 0 && carry_row != kSegNone) {                          // the run still open at the end of the chunk
-        const bool complete = carry_row != next_row;
+        const bool complete = tail_complete;
         const bool is_head = carry_row == first_row && head_partial;
         if (complete && !is_head) emit(carry_row, carry, true);
         else if (complete) {                                           // ends here, began earlier
@@ -250,8 +284,8 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_kernel(const int* __rest
                                                                const float4* __restrict__ g_pix, int accumulate,
                                                                float4* __restrict__ grad_spatial, long Ns,
                                                                int* __restrict__ rec_row, float4* __restrict__ rec_val) {
-    seg_reduce_chunk<C>((long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, *n_entries, row_of, contrib, w_sorted, g_pix,
-                        accumulate, grad_spatial, Ns, rec_row, rec_val);
+    seg_reduce_chunk<C, false>((long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, *n_entries, row_of, contrib, w_sorted,
+                               g_pix, accumulate, grad_spatial, Ns, rec_row, rec_val);
 }
 
 // All views of a batch in ONE launch (blockIdx.y = view): every view reduces its own entries into its own compact
@@ -265,8 +299,8 @@ struct SegViews {
     long n_rows[kViewsPerLaunch];
     long block_start[kViewsPerLaunch];          // first workgroup of the view in the flat list (reduce kernel)
     long total_blocks;
-    const int* ord_of[kViewsPerLaunch];
-    const int* contrib[kViewsPerLaunch];
+    const int* chunk_ord[kViewsPerLaunch];
+    const int* packed[kViewsPerLaunch];
     const float* w_sorted[kViewsPerLaunch];
     const float4* g_pix[kViewsPerLaunch];
     float4* val[kViewsPerLaunch];               // [n_rows] row sums of the view
@@ -290,8 +324,18 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_views_kernel(SegViews a)
         if (i < a.nv && vb >= a.block_start[i]) v = i;                 // block_start ascends
     const long wg = (vb - a.block_start[v]) * 4 + (threadIdx.x >> 6);
     if (wg >= a.chunks[v]) return;                                     // wave-uniform
-    seg_reduce_chunk<1>(wg, threadIdx.x & 63, a.E[v], a.ord_of[v], a.contrib[v], a.w_sorted[v], a.g_pix[v], 0, a.val[v],
-                        a.n_rows[v], a.rec_row[v], a.rec_val[v]);
+    seg_reduce_chunk<1, true>(wg, threadIdx.x & 63, a.E[v], a.chunk_ord[v], a.packed[v], a.w_sorted[v], a.g_pix[v], 0, a.val[v],
+                              a.n_rows[v], a.rec_row[v], a.rec_val[v]);
+}
+
+// ONE view, C right-hand sides (DeepFool's class gradients), over the view's compact index into val[C][n_rows].
+template <int C>
+__global__ __launch_bounds__(256) void gauss_seg_reduce_packed_kernel(long E, const int* __restrict__ chunk_ord,
+                                                                      const int* __restrict__ packed, const float* __restrict__ w_sorted,
+                                                                      const float4* __restrict__ g_pix, float4* __restrict__ val,
+                                                                      long n_rows, int* __restrict__ rec_row, float4* __restrict__ rec_val) {
+    seg_reduce_chunk<C, true>((long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, E, chunk_ord, packed, w_sorted, g_pix, 0,
+                              val, n_rows, rec_row, rec_val);
 }
 
 // Rows that cross chunk boundaries: the chunk where such a row starts adds up its partial records in chunk order.
@@ -344,24 +388,29 @@ __global__ __launch_bounds__(256) void gauss_seg_combine_views_kernel(SegViews a
 struct RowsSum {
     const int* pos[kViewsPerLaunch];
     const float4* val[kViewsPerLaunch];
+    long n_rows[kViewsPerLaunch];               // stride between the right-hand sides of a view's sums
     int nv;
 };
 
+template <int C>
 __global__ __launch_bounds__(256) void gauss_rows_sum_kernel(RowsSum a, long Ns, int accumulate, float4* __restrict__ grad_spatial) {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Ns) return;
     int p[kViewsPerLaunch];
 #pragma unroll
     for (int v = 0; v < kViewsPerLaunch; ++v) p[v] = v < a.nv ? a.pos[v][j] : -1;      // all index loads first
-    float4 s = accumulate ? grad_spatial[j] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int v = 0; v < kViewsPerLaunch; ++v)
-        if (p[v] >= 0) s = f4_add(s, a.val[v][p[v]]);
-    grad_spatial[j] = s;
+    for (int c = 0; c < C; ++c) {
+        float4 s = accumulate ? grad_spatial[(long)c * Ns + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int v = 0; v < kViewsPerLaunch; ++v)
+            if (p[v] >= 0) s = f4_add(s, a.val[v][(long)c * a.n_rows[v] + p[v]]);
+        grad_spatial[(long)c * Ns + j] = s;
+    }
 }
 
-// Row ordinals of a view index: pos[j] = number of non-empty rows before row j, or -1 for an empty row; ord_of[e] =
-// pos[row of entry e]; n_rows = number of non-empty rows. (flags -> exclusive sum -> fix-up)
+// Row ordinals of a view index: pos[j] = number of non-empty rows before row j, or -1 for an empty row; n_rows = number
+// of non-empty rows (flags -> exclusive sum -> fix-up); then the packed entries and the per-chunk first ordinals.
 __global__ __launch_bounds__(256) void view_row_flags_kernel(const int* __restrict__ row_ptr, long Ns, int* __restrict__ flags) {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < Ns) flags[j] = row_ptr[j + 1] > row_ptr[j] ? 1 : 0;
@@ -377,11 +426,15 @@ __global__ __launch_bounds__(256) void view_row_pos_kernel(const int* __restrict
     pos[j] = any ? before : -1;
 }
 
-__global__ __launch_bounds__(256) void view_entry_ord_kernel(const int* __restrict__ row_ptr, long Ns, const int* __restrict__ row_of,
-                                                             const int* __restrict__ pos, long cap, int* __restrict__ ord_of) {
+__global__ __launch_bounds__(256) void view_entry_pack_kernel(const int* __restrict__ row_ptr, long Ns, const int* __restrict__ row_of,
+                                                              const int* __restrict__ contrib, const int* __restrict__ pos, long cap,
+                                                              int* __restrict__ packed, int* __restrict__ chunk_ord) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cap || e >= row_ptr[Ns]) return;
-    ord_of[e] = pos[row_of[e]];
+    const int row = row_of[e];
+    const int start = (e == 0 || row_of[e - 1] != row) ? 1 : 0;
+    packed[e] = ((contrib[e] >> 3) << 1) | start;                  // pixel * 2 + "a row starts here"
+    if (e % kSegChunk == 0) chunk_ord[e / kSegChunk] = pos[row];
 }
 
 // ---- multi-RHS form (DeepFool: the gradients of all class logits of one iteration, deepfool.py:66-96). The index
@@ -554,19 +607,21 @@ extern "C" int nerfail_gauss_bwd_csr(const float* ori_img, const float* x, const
 
 static long view_chunks(long n_entries) { return ((n_entries + kSegChunk - 1) / kSegChunk + 3) / 4 * 4; }
 
-extern "C" size_t nerfail_gauss_view_ranks_workspace_bytes(int64_t Ns) {
+extern "C" size_t nerfail_gauss_view_pack_workspace_bytes(int64_t Ns) {
     if (Ns <= 0 || Ns >= (1L << 31) - 1) return 0;
     size_t bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (int)Ns, (hipStream_t) nullptr);
     return align256((size_t)Ns * 4) + align256(bytes);
 }
 
-extern "C" int nerfail_gauss_view_ranks(const int32_t* row_ptr, const int32_t* row_of, int64_t Ns, int64_t entry_capacity,
-                                        int32_t* pos, int32_t* ord_of, int32_t* n_rows, void* workspace,
-                                        size_t workspace_bytes, void* stream) {
+extern "C" int64_t nerfail_gauss_view_chunks(int64_t n_entries) { return n_entries < 0 ? 0 : view_chunks(n_entries); }
+
+extern "C" int nerfail_gauss_view_pack(const int32_t* row_ptr, const int32_t* row_of, const int32_t* contrib, int64_t Ns,
+                                       int64_t entry_capacity, int32_t* pos, int32_t* packed, int32_t* chunk_ord,
+                                       int32_t* n_rows, void* workspace, size_t workspace_bytes, void* stream) {
     NF_REQUIRE(Ns > 0 && Ns < (1L << 31) - 1 && entry_capacity >= 0, "bad sizes");
-    NF_REQUIRE(row_ptr && row_of && pos && ord_of && n_rows && workspace, "NULL pointer");
-    NF_REQUIRE(workspace_bytes >= nerfail_gauss_view_ranks_workspace_bytes(Ns), "workspace too small (nerfail_gauss_view_ranks_workspace_bytes)");
+    NF_REQUIRE(row_ptr && row_of && contrib && pos && packed && chunk_ord && n_rows && workspace, "NULL pointer");
+    NF_REQUIRE(workspace_bytes >= nerfail_gauss_view_pack_workspace_bytes(Ns), "workspace too small (nerfail_gauss_view_pack_workspace_bytes)");
     hipStream_t s = as_stream(stream);
     int* flags = (int*)workspace;
     void* temp = (char*)workspace + align256((size_t)Ns * 4);
@@ -579,25 +634,25 @@ extern "C" int nerfail_gauss_view_ranks(const int32_t* row_ptr, const int32_t* r
     view_row_pos_kernel<<<dim3(gb), dim3(256), 0, s>>>(row_ptr, Ns, pos, n_rows);
     NF_LAUNCHED("view_row_pos_kernel");
     if (entry_capacity > 0) {
-        view_entry_ord_kernel<<<dim3((unsigned)((entry_capacity + 255) / 256)), dim3(256), 0, s>>>(row_ptr, Ns, row_of, pos,
-                                                                                                  entry_capacity, ord_of);
-        NF_LAUNCHED("view_entry_ord_kernel");
+        view_entry_pack_kernel<<<dim3((unsigned)((entry_capacity + 255) / 256)), dim3(256), 0, s>>>(row_ptr, Ns, row_of, contrib, pos,
+                                                                                                   entry_capacity, packed, chunk_ord);
+        NF_LAUNCHED("view_entry_pack_kernel");
     }
     return NERFAIL_OK;
 }
 
 static bool view_ok(const nerfail_view_index& v, long Ns, long P) {
-    return v.contrib && v.w_sorted && v.ord_of && v.pos && v.n_entries >= 0 && v.n_entries <= 8 * P && v.n_rows >= 0 &&
+    return v.packed && v.w_sorted && v.chunk_ord && v.pos && v.n_entries >= 0 && v.n_entries <= 8 * P && v.n_rows >= 0 &&
            v.n_rows <= v.n_entries && v.n_rows <= Ns && (v.n_entries == 0) == (v.n_rows == 0);
 }
 
-extern "C" size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_index* views, int n_views, int64_t P) {
-    if (views == nullptr || n_views < 1 || P <= 0) return 0;
-    size_t f = (size_t)n_views * P * 4;                                 // per-pixel gradients of the batch
+extern "C" size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_index* views, int n_views, int64_t P, int n_rhs) {
+    if (views == nullptr || n_views < 1 || P <= 0 || n_rhs < 1 || n_rhs > 8) return 0;
+    size_t f = (size_t)n_views * P * 4 * n_rhs;                         // per-pixel gradients of the batch
     for (int v = 0; v < n_views; ++v) {
         if (views[v].n_entries < 0 || views[v].n_rows < 0) return 0;
         const size_t chunks = (size_t)view_chunks(views[v].n_entries);
-        f += chunks * 2 * 4 + chunks * 4 + (size_t)views[v].n_rows * 4;   // record values, record rows, the view's row sums
+        f += chunks * 2 * 4 * n_rhs + chunks * 4 + (size_t)views[v].n_rows * 4 * n_rhs;   // record values, record rows, row sums
     }
     return f;
 }
@@ -627,8 +682,8 @@ extern "C" int nerfail_gauss_bwd_views(const float* ori_img, const float* x, con
         for (int i = 0; i < kViewsPerLaunch; ++i) {
             const nerfail_view_index& vi = views[v0 + (i < nv ? i : 0)];     // (unused slots repeat slot 0: valid pointers)
             const long chunks = i < nv ? view_chunks(vi.n_entries) : 0;
-            a.E[i] = vi.n_entries; a.chunks[i] = chunks; a.n_rows[i] = vi.n_rows;
-            a.ord_of[i] = vi.ord_of; a.contrib[i] = vi.contrib; a.w_sorted[i] = vi.w_sorted;
+            a.E[i] = vi.n_entries; a.chunks[i] = chunks; a.n_rows[i] = r.n_rows[i] = vi.n_rows;
+            a.chunk_ord[i] = vi.chunk_ord; a.packed[i] = vi.packed; a.w_sorted[i] = vi.w_sorted;
             a.g_pix[i] = (const float4*)scratch + (size_t)(v0 + (i < nv ? i : 0)) * P;
             a.rec_val[i] = (float4*)cursor;
             a.rec_row[i] = (int*)(cursor + (size_t)chunks * 8);
@@ -645,10 +700,58 @@ extern "C" int nerfail_gauss_bwd_views(const float* ori_img, const float* x, con
             gauss_seg_combine_views_kernel<<<dim3((unsigned)((max_chunks + 255) / 256), (unsigned)nv), dim3(256), 0, s>>>(a);
             NF_LAUNCHED("gauss_seg_combine_views_kernel");
         }
-        gauss_rows_sum_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, (float4*)grad_spatial);
+        gauss_rows_sum_kernel<1><<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, (float4*)grad_spatial);
         NF_LAUNCHED("gauss_rows_sum_kernel");
     }
     return NERFAIL_OK;
+}
+
+// ONE view, C right-hand sides over the view's compact index: reduce -> combine -> expand through pos
+template <int C>
+static int run_view_multi(const nerfail_view_index& vi, long Ns, long P, float* scratch, float* grad_spatial, hipStream_t s) {
+    const long chunks = view_chunks(vi.n_entries);
+    const float4* g_pix = (const float4*)scratch;
+    float* cursor = scratch + (size_t)P * 4 * C;
+    float4* rec_val = (float4*)cursor;
+    int* rec_row = (int*)(cursor + (size_t)chunks * 8 * C);
+    float4* val = (float4*)(cursor + (size_t)chunks * 8 * C + (size_t)chunks * 4);
+    if (chunks > 0) {
+        gauss_seg_reduce_packed_kernel<C><<<dim3((unsigned)(chunks / 4)), dim3(256), 0, s>>>(
+            vi.n_entries, vi.chunk_ord, vi.packed, vi.w_sorted, g_pix, val, vi.n_rows, rec_row, rec_val);
+        NF_LAUNCHED("gauss_seg_reduce_packed_kernel");
+        gauss_seg_combine_kernel<C><<<dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s>>>(rec_row, rec_val, chunks, 0, val, vi.n_rows);
+        NF_LAUNCHED("gauss_seg_combine_kernel");
+    }
+    RowsSum r;
+    r.nv = 1;
+    for (int i = 0; i < kViewsPerLaunch; ++i) { r.pos[i] = vi.pos; r.val[i] = val; r.n_rows[i] = vi.n_rows; }
+    gauss_rows_sum_kernel<C><<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, 0, (float4*)grad_spatial);
+    NF_LAUNCHED("gauss_rows_sum_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_gauss_bwd_view_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,
+                                            const nerfail_view_index* view, int64_t Ns, int64_t P, float epsilon,
+                                            float* scratch, float* grad_spatial, void* stream) {
+    NF_REQUIRE(Ns > 0 && P > 0, "bad sizes");
+    NF_REQUIRE(n_rhs >= 1 && n_rhs <= 8, "n_rhs must be in 1..8");
+    NF_REQUIRE(ori_img && x && grad_x_rgba && view && scratch && grad_spatial, "NULL pointer");
+    NF_REQUIRE(view_ok(*view, Ns, P), "the view index is incomplete or inconsistent");
+    hipStream_t s = as_stream(stream);
+    const long total = P * n_rhs;
+    gauss_pixel_grad_multi_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x_rgba, P, n_rhs, epsilon, (float4*)scratch);
+    NF_LAUNCHED("gauss_pixel_grad_multi_kernel");
+    switch (n_rhs) {
+        case 1: return run_view_multi<1>(*view, Ns, P, scratch, grad_spatial, s);
+        case 2: return run_view_multi<2>(*view, Ns, P, scratch, grad_spatial, s);
+        case 3: return run_view_multi<3>(*view, Ns, P, scratch, grad_spatial, s);
+        case 4: return run_view_multi<4>(*view, Ns, P, scratch, grad_spatial, s);
+        case 5: return run_view_multi<5>(*view, Ns, P, scratch, grad_spatial, s);
+        case 6: return run_view_multi<6>(*view, Ns, P, scratch, grad_spatial, s);
+        case 7: return run_view_multi<7>(*view, Ns, P, scratch, grad_spatial, s);
+        default: return run_view_multi<8>(*view, Ns, P, scratch, grad_spatial, s);
+    }
 }
 
 extern "C" int nerfail_gauss_bwd_csr_multi(const float* ori_img, const float* x, const float* grad_x_rgba, int n_rhs,
