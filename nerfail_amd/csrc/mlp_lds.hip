@@ -291,18 +291,26 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias_tile(P, 0, t);                                     // later rounds: written by the views layer
 
-    const long ntiles = (a.M + 31) / 32;
-    const long nrounds = (ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4);
-    for (long rnd = 0; rnd < nrounds; ++rnd) {
+    // 32-bit tile counters (the launcher checks M < 2^36): a 64-bit "tile < ntiles" has no scalar compare, so ntiles
+    // was copied into a VGPR pair that then lived - in scratch - through the whole kernel
+    const int ntiles = (int)((a.M + 31) / 32);
+    const int nrounds = (int)((ntiles + (long)gridDim.x * 4 - 1) / ((long)gridDim.x * 4));
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
         // every wave of the workgroup walks the whole stream every round (it moves a quarter of it): a wave without a
         // tile of its own recomputes the last tile and stores nothing
-        const long tile_own = (rnd * gridDim.x + blockIdx.x) * 4 + wave;
-        const long tile = tile_own < ntiles ? tile_own : ntiles - 1;
-        const long sraw = tile * 32 + j;
+        const int tile_own = (int)(((long)rnd * gridDim.x + blockIdx.x) * 4 + wave);
+        const int tile = tile_own < ntiles ? tile_own : ntiles - 1;
+        // (lane-derived values are taken through an opaque copy per tile: hoisted out of the tile loop - "M - j", byte
+        // offsets of the lane, a zero for address extension - they had to live across it and were spilled to scratch)
+        int jj = j;
+        asm volatile("" : "+v"(jj));
+        const long sraw = (long)tile * 32 + jj;
         const long s = sraw < a.M ? sraw : a.M - 1;
 
         float emb[4 * kEmbQuads], demb[4 * kDirQuads];
-        encode_sample(a, s, h, emb, demb);
+        int hh = h;
+        asm volatile("" : "+v"(hh));
+        encode_sample(a, s, hh, emb, demb);
         // The encoding operands are needed at layer 0 (now), at the skip layer (points) and at the views layer (directions),
         // 5 and 9 layers from here. Kept in registers they were spilled to scratch, and a scratch reload drains the
         // LDS-DMA queue (vmcnt retires in order): parked in LDS instead, one conflict-free 16-byte access per quad.
@@ -359,8 +367,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)                                                       // rgb_linear: W/2 -> 3 (RH:118)
             rgb[c] = lds_head<OTV>(Q, c_rgb + c * OTV * 32, h) + c_rgb[3 * OTV * 32 + c];
-        if (h == 0 && sraw < a.M && tile_own < ntiles)
-            reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);
+        int je = j;                                  // recomputed: the sample index need not live through the tile
+        asm volatile("" : "+v"(je));
+        const long sout = (long)tile * 32 + je;
+        if (h == 0 && sout < a.M && tile_own < ntiles)
+            reinterpret_cast<float4*>(a.raw)[sout] = make_float4(rgb[0], rgb[1], rgb[2], alpha);
     }
     lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight when the workgroup's LDS is released
 }
@@ -383,6 +394,7 @@ static int launch_lds(const MlpArgs& a, unsigned blocks, hipStream_t s) {
 }
 
 int launch_mlp_lds(const MlpArgs& a, int W, hipStream_t s) {
+    if (a.M >= (1L << 36)) { set_error("nerfail_mlp_fwd: M must be below 2^36 samples per call"); return NERFAIL_EINVAL; }
     const long ntiles = (a.M + 31) / 32;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
