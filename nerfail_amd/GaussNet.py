@@ -176,6 +176,31 @@ def view_indices(wi, Ns, view_ids=None):
     return out
 
 
+def load_view_indices(map_dir, ids, Ns, save_missing=True):
+    """Per-view indices stored next to the maps they belong to: for every i in `ids` loads
+    `<map_dir>/<i>.idx.pth` (ViewIndex.save) or, if it is not there yet, builds it from `<map_dir>/<i>.pth` (the float32
+    [2,H,W,8] weight / index map dist_to_weight writes, DW:95-97) and stores it. The indices are registered in the cache;
+    returns the view ids to hand to gauss_net.forward / nerfail_s_step (`view_ids=`), which then neither fingerprint nor
+    rebuild anything, whatever batches the DataLoader composes."""
+    import os
+    out = []
+    for i in ids:
+        vid = (os.path.abspath(map_dir), int(i))
+        side = os.path.join(map_dir, '%d.idx.pth' % int(i))
+        if os.path.exists(side):
+            vi = ViewIndex.load(side)
+            if vi.Ns != int(Ns):
+                raise ValueError('%s was built for a table of %d rows, not %d' % (side, vi.Ns, int(Ns)))
+        else:
+            wi = _lib.f32c(torch.load(os.path.join(map_dir, '%d.pth' % int(i)), map_location='cpu'), _cuda())
+            vi = ViewIndex(wi, int(Ns))
+            if save_missing:
+                vi.save(side)
+        register_view_index(vid, vi, Ns)
+        out.append(vid)
+    return out
+
+
 def register_view_index(view_id, index, Ns=None):
     """Put a ViewIndex loaded from disk (ViewIndex.load) into the cache under the caller's view id."""
     _VIEW_CACHE[('id', view_id if isinstance(view_id, (str, bytes, tuple)) else int(view_id), int(Ns or index.Ns))] = index

@@ -30,11 +30,15 @@ def igsm_step(spatial, grad, spatial_init, a=2.0, epsilon=32.0, targeted=False, 
     return res
 
 
-def perturbation_grad(net, spatial, weight_and_index, ori_img, label, batch_total=None, grad_fn=None):
+def perturbation_grad(net, spatial, weight_and_index, ori_img, label, batch_total=None, grad_fn=None, view_ids=None):
     """d(CE(cla, label))/d(spatial) for the views given (AS:317-348). `batch_total` = views in the WHOLE batch
-    (CE is a mean over the batch, so a shard holding k of B views contributes with weight k/B)."""
+    (CE is a mean over the batch, so a shard holding k of B views contributes with weight k/B). `view_ids`: the views'
+    dataset indices - keys of their cached / persisted inverted indices (GaussNet.view_indices, load_view_indices)."""
     s = spatial.detach().clone().requires_grad_(True)
-    x, r, cla, ori, ori_cla = net(s, weight_and_index, ori_img)
+    if view_ids is not None:
+        x, r, cla, ori, ori_cla = net(s, weight_and_index, ori_img, view_ids=view_ids)
+    else:
+        x, r, cla, ori, ori_cla = net(s, weight_and_index, ori_img)
     lab = label.to(cla.device).broadcast_to([cla.shape[0]])
     if grad_fn is not None:
         loss = grad_fn(cla, lab)
@@ -44,7 +48,7 @@ def perturbation_grad(net, spatial, weight_and_index, ori_img, label, batch_tota
     return s.grad, loss.detach(), cla.detach()
 
 
-def sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group=None, timing=None):
+def sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group=None, timing=None, view_ids=None):
     """d(mean CE over the WHOLE batch)/d(spatial), identical on every rank: this rank differentiates its contiguous
     share of the batch's views (weight k/B), then ONE all-reduce sums the [P,H,W,4] gradient (C1).
     `timing`: optional dict; gets HIP events around the collective ('allreduce_events') for bench.py."""
@@ -52,7 +56,8 @@ def sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, gr
     B = weight_and_index.shape[0]
     lo, hi = sharding.shard_range(B, rank, world)
     if hi > lo:
-        g, loss, _ = perturbation_grad(net, spatial, weight_and_index[lo:hi], ori_img[lo:hi], label, batch_total=B)
+        g, loss, _ = perturbation_grad(net, spatial, weight_and_index[lo:hi], ori_img[lo:hi], label, batch_total=B,
+                                       view_ids=None if view_ids is None else list(view_ids)[lo:hi])
     else:                                   # more ranks than views: this rank only takes part in the sum
         g = torch.zeros_like(spatial)
         loss = torch.zeros((), device=spatial.device)
@@ -69,22 +74,24 @@ def sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, gr
 
 
 def nerfail_s_step(net, spatial, spatial_init, weight_and_index, ori_img, label, a=2.0, epsilon=32.0,
-                   targeted=False, group=None, timing=None):
+                   targeted=False, group=None, timing=None, view_ids=None):
     """One NeRFail-S iteration (AS:304-392) on one batch of views. Sharded over ranks when torch.distributed is up:
     every rank ends with the identical perturbation tensor."""
-    g, loss = sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group, timing)
+    g, loss = sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group, timing, view_ids)
     return igsm_step(spatial, g, spatial_init, a, epsilon, targeted), loss
 
 
 def nerfail_s_loop(net, spatial, spatial_init, batches, label, iters, a=2.0, epsilon=32.0, targeted=False, group=None,
                    on_iter=None):
     """The AS:278-392 loop shape of BASELINE configs[2]: `iters` passes over `batches` (list of (weight_and_index,
-    ori_img) per batch of views), the perturbation updated after EVERY batch (sequential dependence, AS:306-392).
+    ori_img[, view_ids]) per batch of views), the perturbation updated after EVERY batch (sequential dependence, AS:306-392).
     Returns the final perturbation; `on_iter(it, b, s, loss)` sees every iterate."""
     s = spatial
     for it in range(iters):
-        for b, (wi, ori) in enumerate(batches):
-            s, loss = nerfail_s_step(net, s, spatial_init, wi, ori, label, a, epsilon, targeted, group)
+        for b, batch in enumerate(batches):
+            wi, ori = batch[0], batch[1]
+            s, loss = nerfail_s_step(net, s, spatial_init, wi, ori, label, a, epsilon, targeted, group,
+                                     view_ids=batch[2] if len(batch) > 2 else None)
             if on_iter is not None:
                 on_iter(it, b, s, loss)
     return s

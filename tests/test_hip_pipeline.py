@@ -121,6 +121,19 @@ def test_pipeline_through_files(tmp_path):
     assert np.array_equal(d[..., 3], np.zeros_like(d[..., 3])) and np.abs(d[..., :3]).max() <= 4.0 and np.abs(d).max() > 0
     assert np.isfinite(float(loss))
 
+    # ---- the same two steps with the views' inverted indices stored next to their maps (N2): built and saved on the
+    # first call, loaded from <i>.idx.pth on the second; the iterates are the same bits either way
+    from nerfail_amd import GaussNet as G
+    mdir = os.path.join(exp, 'index_and_weight', 'test')
+    for rnd in range(2):
+        G._VIEW_CACHE.clear(); G._BATCH_KEYS.clear()
+        ids = G.load_view_indices(mdir, range(4), s0.numel() // 4)
+        assert all(os.path.exists(os.path.join(mdir, '%d.idx.pth' % i)) for i in range(4))
+        s2 = s0.clone()
+        for _ in range(2):
+            s2, _ = nerfail_s_step(net, s2, s0, wi.clone(), ori, torch.tensor(3, device=dev()), a=2.0, epsilon=32.0, view_ids=ids)
+        assert torch.equal(s2, s)
+
 
 def test_retrain_on_attacked_data_round_trip(tmp_path):
     """SURVEY 8f N3 - the paper's closing loop at toy size: a Blender-format scene on disk -> load_blender_data -> a few
