@@ -78,11 +78,12 @@ def kernel_source_hash():
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, which='avg'):
     """HBM(+Infinity Cache) bytes per launch of a kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 +
-    WRITE_SIZE, MI355X_MICROARCH.md; tools/pmc_traffic.py writes the file). PMC counters cannot be read from inside this
-    process, so the number is a stored measurement: it is reported ONLY if the file was taken from the very kernel
-    sources this run uses (csrc hash) - otherwise null, with the reason."""
+    WRITE_SIZE, MI355X_MICROARCH.md; tools/profile_bench.sh + tools/pmc_summary.py write the file). PMC counters cannot be
+    read from inside this process, so the number is a stored measurement: it is reported ONLY if the file was taken from
+    the very kernel sources this run uses (csrc hash) - otherwise null, with the reason. which = 'avg' (mean over the
+    profiled command's launches) or 'max' (its largest launch: for kernels that also run at smaller sizes there)."""
     try:
         pmc = json.load(open(PMC_FILE))
     except (OSError, ValueError):
@@ -92,8 +93,12 @@ def pmc_traffic(kernel_substr):
                                                                           kernel_source_hash())
     for name, v in pmc.get('kernels', {}).items():
         if kernel_substr in name:
-            return (v['fetch_bytes_per_launch_corrected'] + v['write_bytes_per_launch'],
-                    {'file': 'profiles/' + os.path.basename(PMC_FILE), 'command': pmc.get('command'), 'csrc_sha16': pmc.get('csrc_sha16')})
+            f = v['fetch_bytes_per_launch_corrected' if which == 'avg' else 'fetch_bytes_max_launch_corrected']
+            w = v['write_bytes_per_launch' if which == 'avg' else 'write_bytes_max_launch']
+            if f is None or w is None:
+                return None, 'kernel missing from one of the two counter passes'
+            return f + w, {'file': 'profiles/' + os.path.basename(PMC_FILE), 'command': pmc.get('command'),
+                           'csrc_sha16': pmc.get('csrc_sha16'), 'launch': which}
     return None, 'kernel not in ' + os.path.basename(PMC_FILE)
 
 
@@ -409,7 +414,7 @@ def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
         ms = e0.elapsed_time(e1) / n
         traffic, src = 0.0, None
         for k in kernels:                                     # PMC bytes per launch (every kernel launches once per call)
-            t, src = pmc_traffic(k)
+            t, src = pmc_traffic(k, 'max')                    # the 8-view batch is these kernels' largest launch
             traffic = None if (t is None or traffic is None) else traffic + t
         out[name] = {'ms_per_call': ms, 'kernels': list(kernels), 'algorithmic_bytes_per_call': alg,
                      'roofline': {'bound': 'hbm', 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
