@@ -24,3 +24,18 @@ def render_inputs():
     focal, K = synth.lego_intrinsics(RH_, RW_)
     c2w = synth.pose_spherical(-60.0, -30.0, 4.0)[:3, :4]
     return dict(K=K, c2w=c2w, seed_coarse=51, seed_fine=52)
+
+
+# cfg5's loop shape (BASELINE.json configs[4]: attack_NeRFail_S over many views for many iterations at 1/2/4/8 GPUs),
+# scaled down: 9 views in 3 batches of 3 (each batch split 2 + 1 over two ranks), 4 iterations, views named by dataset id
+LOOP_VIEWS, LOOP_BATCH, LOOP_ITERS = 9, 3, 4
+
+
+def loop_inputs():
+    rs = np.random.RandomState(17)
+    s0 = np.zeros((P, H, W, 4), np.float32)
+    s0[..., 3] = np.where(rs.uniform(size=(P, H, W)) < 0.85, 255.0, 0.0)
+    ori = synth.disc_alpha_image(LOOP_VIEWS, H, W, seed=18)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(LOOP_VIEWS, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, (LOOP_VIEWS, H, W, 8)).astype(np.float32)
+    return dict(s0=s0, ori=ori, dist_and_index=np.stack([dist, idx], 1))

@@ -52,6 +52,19 @@ def main(out_dir):
         out['s_it%d' % it] = s.cpu().numpy()
     out['wi'] = wi.cpu().numpy()
 
+    # ---- cfg5's loop shape: nerfail_s_loop over 3 batches x 4 iterations, views named by dataset id (per-view indices
+    # are built once, on the rank that owns the view in its batch's split)
+    lp = PB.loop_inputs()
+    wi_l, _ = create_gauss_w(dev, 0.02)(T(lp['dist_and_index']))
+    ori_l, s0_l = T(lp['ori']), T(lp['s0'])
+    batches = [(wi_l[b:b + PB.LOOP_BATCH].contiguous(), ori_l[b:b + PB.LOOP_BATCH].contiguous(), list(range(b, b + PB.LOOP_BATCH)))
+               for b in range(0, PB.LOOP_VIEWS, PB.LOOP_BATCH)]
+    trace = []
+    s_l = attack.nerfail_s_loop(net, s0_l, s0_l, batches, label, PB.LOOP_ITERS, PB.A, PB.EPS, False,
+                                on_iter=lambda it, b, s_, loss_: trace.append(s_.cpu().numpy()))
+    out['loop_s'] = s_l.cpu().numpy()
+    out['loop_trace'] = np.stack(trace).astype(np.int8)          # iterates are multiples of A within +-EPS: exact in int8
+
     # ---- render: this rank's ray range of one view (D=8 W=256 coarse+fine, 64+128 samples), no collective
     r = PB.render_inputs()
 

@@ -48,6 +48,23 @@ def test_attack_step_two_ranks_identical_and_equal_to_one_rank(runs):
     assert (s[..., :3][a['s0'][..., 3] == 0] == 0).all()
 
 
+def test_cfg5_loop_shape_two_ranks(runs):
+    """BASELINE configs[4]'s loop (attack_NeRFail_S: batches of views, perturbation updated after every batch, many
+    iterations) at 2 ranks: nerfail_s_loop with the views of each batch split over the ranks and named by dataset id.
+    Every iterate is identical on both ranks; against the 1-rank run the sign step may differ only where the gradient is
+    at rounding level (the 2-rank sum adds the views' gradients in another order)."""
+    one, two = runs
+    n_steps = PB.LOOP_ITERS * (PB.LOOP_VIEWS // PB.LOOP_BATCH)
+    assert two[0]['loop_trace'].shape[0] == n_steps
+    assert np.array_equal(two[0]['loop_trace'], two[1]['loop_trace']) and np.array_equal(two[0]['loop_s'], two[1]['loop_s'])
+    diff = two[0]['loop_trace'] != one['loop_trace']
+    print('cfg5 loop, 2 ranks vs 1: differing elements per step', diff.reshape(n_steps, -1).mean(1).max())
+    assert diff.reshape(n_steps, -1).mean(1).max() < 2e-3
+    s, s0 = two[0]['loop_s'], PB.loop_inputs()['s0']
+    assert np.array_equal(s[..., 3], s0[..., 3]) and np.abs(s[..., :3]).max() <= min(PB.EPS, PB.A * n_steps)
+    assert (s[..., :3] != 0).mean() > 0.3                                  # the loop really moved the perturbation
+
+
 def test_attack_gradient_matches_oracle(runs):
     """The all-reduced gradient against the CPU restatement: oracle gauss forward -> torch CPU cold tail + CE (mean over
     the whole batch) -> oracle gauss backward (AS:317-348 / GN:53-157)."""
