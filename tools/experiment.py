@@ -21,12 +21,12 @@ from nerfail_amd import build as B  # noqa: E402
 EXPERIMENTS = {
     'lds_base': ('mlp_lds.hip', [], []),
     'lds_gpm2': ('mlp_lds.hip', [], ['-DNF_LDS_GPM=2']),
-    'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, h, emb, demb);\n',
+    'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, hh, emb, demb);\n',
                                    '        for (int i_ = 0; i_ < 4 * kEmbQuads; ++i_) emb[i_] = 0.25f * (float)(lane & 3) + (float)s * 1e-9f;\n'
                                    '        for (int i_ = 0; i_ < 4 * kDirQuads; ++i_) demb[i_] = 0.5f;\n')], []),
-    'lds_nodma': ('mlp_lds.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + piece) * kPiece),\n'
-                                   '                                         (lds_void_t*)(ring + (slot * C::GP + piece) * kPiece), 16, 0, 0);\n',
-                                   '        asm volatile("" :: "s"(piece));\n')], []),
+    'lds_nodma': ('mlp_lds.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + first) * kPiece),\n'
+                                   '                                         (lds_void_t*)(ring + (slot * C::GP + first) * kPiece), 16, (I % 4) * kPiece * 4, 0);\n',
+                                   '        asm volatile("" :: "s"(first));\n')], []),
     'lds_nobarrier': ('mlp_lds.hip', [('        __builtin_amdgcn_s_barrier();\n        asm volatile("" ::: "memory");\n',
                                        '        asm volatile("" ::: "memory");\n')], []),
     # shader-clock stamps of one tile's phases -> raw[(block*4 + wave)] as 4 uint32 deltas (timing only, outputs destroyed)
@@ -39,17 +39,17 @@ EXPERIMENTS = {
          '        const unsigned long long c2_ = clock64();\n        // pts_linears[l] (l < D) / feature_linear (l == D): out += W_l relu(in).'),
         ('        // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q\'s first tiles',
          '        const unsigned long long c3_ = clock64();\n        // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q\'s first tiles'),
-        ('        if (h == 0 && sraw < a.M && tile_own < ntiles)\n'
-         '            reinterpret_cast<float4*>(a.raw)[sraw] = make_float4(rgb[0], rgb[1], rgb[2], alpha);\n',
+        ('        if (h == 0 && sout < a.M && tile_own < ntiles)\n'
+         '            reinterpret_cast<float4*>(a.raw)[sout] = make_float4(rgb[0], rgb[1], rgb[2], alpha);\n',
          '        const unsigned long long c4_ = clock64();\n'
          '        if (rnd == nrounds - 2 && lane == 0) {\n'
          '            unsigned* o_ = reinterpret_cast<unsigned*>(a.raw) + (blockIdx.x * 4 + wave) * 8;\n'
          '            o_[0] = (unsigned)(c1_ - c0_); o_[1] = (unsigned)(c2_ - c1_); o_[2] = (unsigned)(c3_ - c2_); o_[3] = (unsigned)(c4_ - c3_);\n'
          '            o_[4] = __float_as_uint(rgb[0] + rgb[1] + rgb[2] + alpha); o_[5] = (unsigned)wall_clock64();\n'
          '        }\n')], []),
-    'lds_nobias': ('mlp_lds.hip', [('                    if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1);\n', ''),
+    'lds_nobias': ('mlp_lds.hip', [('                [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); },\n', '                [&](int q) {},\n'),
                                    ('            bias_tile(in, l + 1, NT - 1);\n', '')], []),
-    'lds_norelu': ('mlp_lds.hip', [('in[q >> 2][4 * (q & 3) + e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);', ';')], []),
+    'lds_norelu': ('mlp_lds.hip', [('b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);', 'b[e] = in[q >> 2][4 * (q & 3) + e];')], []),
     'lds_noread': ('mlp_lds.hip', [('        for (int t = 0; t < C::HS; ++t) fr[t] = lds_read4(rl + (rd + t) * kPiece);\n    }\n    __device__ __forceinline__ void start()',
                                     '        for (int t = 0; t < C::HS; ++t) asm volatile("" : "+v"(fr[t]));\n    }\n    __device__ __forceinline__ void start()')], []),
     # shader-clock stamp at the end of EVERY step, kept in the 64 lanes of one VGPR (v_writelane: no memory traffic);
@@ -90,10 +90,6 @@ EXPERIMENTS = {
     'sf_nomerge': ('sampling.hip', [('                if (p <= n && (is_c ? (o < v) : (o <= v))) lo = p;\n            }\n', '                if (p == -5 && (is_c ? (o < v) : (o <= v))) lo = p;\n                break;\n            }\n')], []),
     'sf_noinvert': ('sampling.hip', [('        if (p <= n && (STRICT ? o < v : o <= v)) pos = p;\n    }\n', '        if (p <= n && (STRICT ? o < v : o <= v)) pos = p;\n        break;\n    }\n')], []),
     'sf_noscan': ('sampling.hip', [('        const double incl = wave_scan_add_f64((double)pdf, lane) + carry;\n', '        const double incl = (double)pdf * (double)(lane + 1) + carry;\n')], []),
-    'lds_noheads': ('mlp_lds.hip', [('    return s + __shfl_xor(s, 32, 64);\n}\n\n// SKIP:', '    return w[h];\n}\n\n// SKIP:'),
-                                    ('        __builtin_amdgcn_sched_barrier(0);\n    }\n    return', '    }\n    return'),
-                                    ('            for (int e = 0; e < 4; ++e) s = fmaf(wv[e], relu_bits(x[t][4 * r4 + e]), s);\n',
-                                     '            if (t > 99) s += wv[0];\n')], []),
 }
 
 
