@@ -329,6 +329,26 @@ def attack_bench(dev, iters=5):
             'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
 
+    # the reference's DataLoader hands out a NEW map tensor every iteration (MyDataset.py:199-204).
+    # The per-view indices survive that; what it costs is recognising the views - a content fingerprint of the maps
+    # (one extra read of them) - unless the loop names its views (`view_ids`, the dataset index the loader returns).
+    fresh = [wi.clone() for _ in range(iters + 1)]
+    for tag, ids in (('fingerprinted', None), ('view_ids', list(range(B)))):
+        it_no = [0]
+
+        def one_iter_fresh(s, ids=ids):
+            w_new = fresh[it_no[0] % len(fresh)]
+            it_no[0] += 1
+            st = s.detach().requires_grad_(True)
+            x, x_rgba = gauss_gather(st, w_new, ori, None, None, True, ids)
+            x_rgba.backward(G)
+            return igsm_step(st.detach(), st.grad, s_init, 2.0, 32.0, False)
+        dt = timed(one_iter_fresh, s_init.clone())
+        out['gauss_path_fresh_map_tensor_every_iteration_' + tag] = {
+            'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
+            'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
+    del fresh
     out['gauss_kernels'] = gauss_kernel_rooflines(dev, wi, ori, s_init, G)
 
     torch.manual_seed(0)
