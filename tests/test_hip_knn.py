@@ -1,5 +1,6 @@
 """-m gpu: exact 8-NN build through the C ABI, BIT-EXACT against oracle/knn.py (indices and distances)."""
 import numpy as np
+import torch
 import pytest
 
 import synth
@@ -129,3 +130,18 @@ def test_knn_far_queries_on_view_geometry():
         assert np.array_equal(grid[0].reshape(-1, 8)[sel], od) and np.array_equal(grid[1].reshape(-1, 8)[sel], oi.astype(np.float32))
         far = grid[0][..., 0] > 0.5
         assert 0.2 < far.mean() < 0.8                                # the far-query path really ran (0.39 and 0.26 here)
+
+
+def test_knn_full_size_view_geometry_grid_equals_brute_force():
+    """BASELINE-size map build on the geometry of a real view: all 640 000 queries of an 800 x 800 view (31 % of them
+    background pixels on the near plane) against the 1.92 M points of 3 base views - the grid search (near path + coarse
+    far path) returns exactly what the brute-force scan returns, distances and indices, every query."""
+    from nerfail_amd.create_index_and_dist import index_and_dist
+    H = W = 800
+    S = T(np.stack([synth.sphere_view_points(H, W, th) for th in (-120., 0., 120.)]).reshape(-1, 3))
+    Q = T(synth.sphere_view_points(H, W, 45.).reshape(H, W, 3))
+    grid = index_and_dist(Q, S, method='grid')
+    brute = index_and_dist(Q, S, method='brute')
+    assert torch.equal(grid, brute)
+    far = (grid[0][..., 0] > 0.5).float().mean().item()
+    assert 0.2 < far < 0.8
