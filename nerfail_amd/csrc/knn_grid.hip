@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void cell_start_kernel(const unsigned* __restr
     cell_start[c] = (int)lo;
 }
 
-constexpr int kCoarse = 4;            // fine cells per coarse cell and axis
+constexpr int kCoarse = 4;
+constexpr int kSuper = 4;         // coarse cells per side of a super block
 constexpr int kShellCap = 3;          // fine shells (beyond the query's own cell) before the coarse search takes over
 
 // points per coarse cell = sum over its 16 x-rows of 4 consecutive fine cells
@@ -125,6 +126,18 @@ __global__ __launch_bounds__(256) void coarse_count_kernel(const int* __restrict
             const long row = ((long)z * G + y) * G;
             n += cell_start[row + x1] - cell_start[row + x0];
         }
+    cnt[c] = n;
+}
+
+// third level: points per block of kSuper^3 coarse cells (a few hundred blocks: the far-query search ranks ALL of them)
+__global__ __launch_bounds__(256) void super_count_kernel(const int* __restrict__ coarse_cnt, int Gc, int Gs, int* __restrict__ cnt) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (long)Gs * Gs * Gs) return;
+    const int X = (int)(c % Gs), Y = (int)((c / Gs) % Gs), Z = (int)(c / ((long)Gs * Gs));
+    int n = 0;
+    for (int z = Z * kSuper; z < min(Z * kSuper + kSuper, Gc); ++z)
+        for (int y = Y * kSuper; y < min(Y * kSuper + kSuper, Gc); ++y)
+            for (int x = X * kSuper; x < min(X * kSuper + kSuper, Gc); ++x) n += coarse_cnt[((long)z * Gc + y) * Gc + x];
     cnt[c] = n;
 }
 
@@ -174,7 +187,7 @@ __device__ __forceinline__ void scan_points(const float4* __restrict__ sorted, i
 
 __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict__ queries, long nq, const Grid* __restrict__ gp,
                                                         const float4* __restrict__ sorted, const int* __restrict__ cell_start,
-                                                        const int* __restrict__ coarse_cnt, float* __restrict__ dist, float* __restrict__ idx_f,
+                                                        const int* __restrict__ coarse_cnt, const int* __restrict__ super_cnt, float* __restrict__ dist, float* __restrict__ idx_f,
                                                         int* __restrict__ idx_i) {
     const long qi = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
@@ -187,7 +200,13 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
     for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
 
     bool done = false;
-    for (int R = 0; R < G && R <= kShellCap; ++R) {
+    // a query more than kShellCap cells outside the grid cannot finish in the shell phase (its clamped cell's shells stay
+    // farther than that from it): it goes straight to the ranked search (whatever the shells found is discarded there anyway)
+    const float ext = g.cs * (float)G;
+    const float outside = fmaxf(fmaxf(fmaxf(g.ox - qx, qx - (g.ox + ext)), fmaxf(g.oy - qy, qy - (g.oy + ext))),
+                                fmaxf(g.oz - qz, qz - (g.oz + ext)));
+    const bool skip_shells = outside > (float)(kShellCap + 1) * g.cs;
+    for (int R = 0; R < G && R <= kShellCap && !skip_shells; ++R) {
         const int z0 = max(cz - R, 0), z1 = min(cz + R, G - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, G - 1);
         const int x0 = max(cx - R, 0), x1 = min(cx + R, G - 1);
@@ -225,68 +244,70 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
         }
     }
     if (!done) {
-        // ---- far query: coarse shells with empty-cell and box-distance pruning (a fresh top-8: no duplicates)
+        // ---- far query (a background pixel's point on the near plane: one to two units from every point, tens of cells):
+        // no shell walk - every block of kSuper^3 coarse cells is RANKED by the distance of its box. The nearest non-empty
+        // block seeds the top-8; after that a block, a coarse cell or a fine cell is opened only if its box can still
+        // hold a point nearer than the current 8th (strict, same 0.999 safety factor as the stopping rule). Every block
+        // is considered, so the result is exact whatever the visiting order (the key (d2, index) is total); walking
+        // coarse SHELLS instead cost ~30 000 empty-cell checks per query (7.7 ms per view).
 #pragma unroll
         for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
-        const int Gc = (G + kCoarse - 1) / kCoarse;
-        const float ccs = g.cs * (float)kCoarse;
-        const int CX = cx / kCoarse, CY = cy / kCoarse, CZ = cz / kCoarse;
-        for (int R = 0; R < Gc; ++R) {
-            const int Z0 = max(CZ - R, 0), Z1 = min(CZ + R, Gc - 1);
-            const int Y0 = max(CY - R, 0), Y1 = min(CY + R, Gc - 1);
-            const int X0 = max(CX - R, 0), X1 = min(CX + R, Gc - 1);
-            for (int Z = Z0; Z <= Z1; ++Z) {
-                const bool zface = (Z == CZ - R) || (Z == CZ + R);
-                for (int Y = Y0; Y <= Y1; ++Y) {
-                    const bool yface = zface || (Y == CY - R) || (Y == CY + R);
-                    const int step = yface ? 1 : max(X1 - X0, 1);        // off the faces only the two end cells belong to the shell
-                    for (int X = X0; X <= X1; X += step) {
-                        if (!yface && X != CX - R && X != CX + R) continue;
-                        if (coarse_cnt[((long)Z * Gc + Y) * Gc + X] == 0) continue;
-                        // squared distance from the query to the coarse cell's box: a lower bound for every point inside
-                        const float bx0 = g.ox + (float)X * ccs, by0 = g.oy + (float)Y * ccs, bz0 = g.oz + (float)Z * ccs;
-                        const float ddx = fmaxf(fmaxf(bx0 - qx, qx - (bx0 + ccs)), 0.f);
-                        const float ddy = fmaxf(fmaxf(by0 - qy, qy - (by0 + ccs)), 0.f);
-                        const float ddz = fmaxf(fmaxf(bz0 - qz, qz - (bz0 + ccs)), 0.f);
-                        const float md = 0.999f * sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-                        if (top.d[7] < md * md) continue;                // strict, with the same safety factor as the stopping rule
-                        // inside: the same box test per fine cell (a dense surface seen from afar has its 8th distance
-                        // within a cell diagonal of the first: most of a coarse cell's points cannot enter any more)
-                        const int fx0 = X * kCoarse, fx1 = min(fx0 + kCoarse, G);
-                        for (int z = Z * kCoarse; z < min(Z * kCoarse + kCoarse, G); ++z) {
-                            const float cz0 = g.oz + (float)z * g.cs;
-                            const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
-                            for (int y = Y * kCoarse; y < min(Y * kCoarse + kCoarse, G); ++y) {
-                                const float cy0 = g.oy + (float)y * g.cs;
-                                const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
-                                const float eyz = ey * ey + ez * ez;
-                                const long row = ((long)z * G + y) * G;
-                                int b = cell_start[row + fx0];
-                                for (int x = fx0; x < fx1; ++x) {
-                                    const int e = cell_start[row + x + 1];
-                                    const float cx0 = g.ox + (float)x * g.cs;
-                                    const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
-                                    const float m = 0.999f * sqrtf(ex * ex + eyz);
-                                    if (e > b && !(top.d[7] < m * m)) scan_points(sorted, b, e, qx, qy, qz, top);
-                                    b = e;
-                                }
-                            }
-                        }
+        const int Gc = (G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper;
+        const float ccs = g.cs * (float)kCoarse, scs = ccs * (float)kSuper;
+        auto box_d2 = [&](float x0, float y0, float z0, float size) {      // squared distance from the query to an axis-aligned cube
+            const float ddx = fmaxf(fmaxf(x0 - qx, qx - (x0 + size)), 0.f);
+            const float ddy = fmaxf(fmaxf(y0 - qy, qy - (y0 + size)), 0.f);
+            const float ddz = fmaxf(fmaxf(z0 - qz, qz - (z0 + size)), 0.f);
+            return ddx * ddx + ddy * ddy + ddz * ddz;
+        };
+        auto cannot_improve = [&](float d2box) {                              // lower bound of the box, shrunk by the safety factor
+            const float md = 0.999f * sqrtf(d2box);
+            return top.d[7] < md * md;
+        };
+        auto visit_coarse = [&](int X, int Y, int Z) {                        // the fine cells of one coarse cell, each box-tested
+            const int fx0 = X * kCoarse, fx1 = min(fx0 + kCoarse, G);
+            for (int z = Z * kCoarse; z < min(Z * kCoarse + kCoarse, G); ++z) {
+                const float cz0 = g.oz + (float)z * g.cs;
+                const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
+                for (int y = Y * kCoarse; y < min(Y * kCoarse + kCoarse, G); ++y) {
+                    const float cy0 = g.oy + (float)y * g.cs;
+                    const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
+                    const float eyz = ey * ey + ez * ez;
+                    const long row = ((long)z * G + y) * G;
+                    int b = cell_start[row + fx0];
+                    for (int x = fx0; x < fx1; ++x) {
+                        const int e = cell_start[row + x + 1];
+                        const float cx0 = g.ox + (float)x * g.cs;
+                        const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
+                        if (e > b && !cannot_improve(ex * ex + eyz)) scan_points(sorted, b, e, qx, qy, qz, top);
+                        b = e;
                     }
                 }
             }
-            float bound = INFINITY;
-            if (CX - R > 0) bound = fminf(bound, qx - (g.ox + (float)(CX - R) * ccs));
-            if (CX + R < Gc - 1) bound = fminf(bound, (g.ox + (float)(CX + R + 1) * ccs) - qx);
-            if (CY - R > 0) bound = fminf(bound, qy - (g.oy + (float)(CY - R) * ccs));
-            if (CY + R < Gc - 1) bound = fminf(bound, (g.oy + (float)(CY + R + 1) * ccs) - qy);
-            if (CZ - R > 0) bound = fminf(bound, qz - (g.oz + (float)(CZ - R) * ccs));
-            if (CZ + R < Gc - 1) bound = fminf(bound, (g.oz + (float)(CZ + R + 1) * ccs) - qz);
-            if (bound == INFINITY) break;
-            if (bound > 0.f) {
-                const float sb = 0.999f * bound;
-                if (top.d[7] < sb * sb) break;
-            }
+        };
+        auto visit_super = [&](int SX, int SY, int SZ) {
+            for (int Z = SZ * kSuper; Z < min(SZ * kSuper + kSuper, Gc); ++Z)
+                for (int Y = SY * kSuper; Y < min(SY * kSuper + kSuper, Gc); ++Y)
+                    for (int X = SX * kSuper; X < min(SX * kSuper + kSuper, Gc); ++X) {
+                        if (coarse_cnt[((long)Z * Gc + Y) * Gc + X] == 0) continue;
+                        if (cannot_improve(box_d2(g.ox + (float)X * ccs, g.oy + (float)Y * ccs, g.oz + (float)Z * ccs, ccs))) continue;
+                        visit_coarse(X, Y, Z);
+                    }
+        };
+        int best = -1;
+        float best_d2 = INFINITY;
+        for (int S = 0; S < Gs * Gs * Gs; ++S) {
+            if (super_cnt[S] == 0) continue;
+            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
+            const float d2 = box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs);
+            if (d2 < best_d2) { best_d2 = d2; best = S; }
+        }
+        if (best >= 0) visit_super(best % Gs, (best / Gs) % Gs, best / (Gs * Gs));
+        for (int S = 0; S < Gs * Gs * Gs; ++S) {
+            if (S == best || super_cnt[S] == 0) continue;
+            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
+            if (cannot_improve(box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs))) continue;
+            visit_super(SX, SY, SZ);
         }
     }
 #pragma unroll
@@ -307,6 +328,7 @@ static int grid_dim_for(long n) {
 }
 
 static size_t coarse_cells(int G) { const size_t Gc = (size_t)(G + kCoarse - 1) / kCoarse; return Gc * Gc * Gc; }
+static size_t super_cells(int G) { const size_t Gc = (size_t)(G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper; return Gs * Gs * Gs; }
 
 static size_t knn_cub_temp(long n) {
     size_t bytes = 0;
@@ -325,7 +347,7 @@ extern "C" size_t nerfail_knn8_grid_workspace_bytes(int64_t n_points) {
     const size_t ncells = (size_t)G * G * G;
     return al256(256) /* bbox + Grid */ + 4 * al256((size_t)n_points * 4) /* keys in/out, vals in/out */ +
            al256((size_t)n_points * 16) /* sorted float4 */ + al256((ncells + 1) * 4) + al256(coarse_cells(G) * 4) +
-           al256(knn_cub_temp(n_points));
+           al256(super_cells(G) * 4) + al256(knn_cub_temp(n_points));
 }
 
 extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* points, int64_t n_points, float* dist,
@@ -352,6 +374,7 @@ extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const 
     float4* sorted = (float4*)ws; ws += al256((size_t)n * 16);
     int* cell_start = (int*)ws; ws += al256((size_t)(ncells + 1) * 4);
     int* coarse_cnt = (int*)ws; ws += al256(coarse_cells(G) * 4);
+    int* super_cnt = (int*)ws; ws += al256(super_cells(G) * 4);
     void* temp = ws;
     size_t temp_bytes = knn_cub_temp(n);
 
@@ -374,8 +397,11 @@ extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const 
     const int Gc = (G + kCoarse - 1) / kCoarse;
     coarse_count_kernel<<<dim3((unsigned)((coarse_cells(G) + 255) / 256)), dim3(256), 0, s>>>(cell_start, G, Gc, coarse_cnt);
     NF_LAUNCHED("coarse_count_kernel");
+    const int Gs = (Gc + kSuper - 1) / kSuper;
+    super_count_kernel<<<dim3((unsigned)((super_cells(G) + 255) / 256)), dim3(256), 0, s>>>(coarse_cnt, Gc, Gs, super_cnt);
+    NF_LAUNCHED("super_count_kernel");
     knn8_grid_kernel<<<dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s>>>(queries, n_queries, gp, sorted, cell_start,
-                                                                                  coarse_cnt, dist, idx_f32, idx_i32);
+                                                                                  coarse_cnt, super_cnt, dist, idx_f32, idx_i32);
     NF_LAUNCHED("knn8_grid_kernel");
     return NERFAIL_OK;
 }

@@ -85,6 +85,10 @@ EXPERIMENTS = {
         ('            default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;\n        }\n    }\n',
          '            default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;\n        }\n    }\n'
          '    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;\n')], []),
+    # K8 grid resolution: cells per axis = scale * cbrt(n) (1.5: 7.6 ms, 2.0: 7.7 ms per rendered-view map against 8.3 ms; shell
+    # points 2.0 / 1.0 ms against 1.3 ms - no clear winner, the search is latency bound)
+    'knn_g15': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(1.5 * cbrt((double)n));')], []),
+    'knn_g20': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(2.0 * cbrt((double)n));')], []),
     # K6 sample_fine pricing: no output stores / no merge search / no inverse-cdf search / no double-precision scan
     'sf_nostore': ('sampling.hip', [('    auto emit = [&](int rank, float z) {\n', '    auto emit = [&](int rank, float z) {\n        if (rank != -12345) return;\n')], []),
     'sf_nomerge': ('sampling.hip', [('                if (p <= n && (is_c ? (o < v) : (o <= v))) lo = p;\n            }\n', '                if (p == -5 && (is_c ? (o < v) : (o <= v))) lo = p;\n                break;\n            }\n')], []),
