@@ -241,15 +241,16 @@ def test_sample_fine_sorted_and_matches_oracle():
         assert rel_err(N(r[k]), ref[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('nc,nf', [(64, 128), (8, 5), (33, 70), (100, 300)])
 @pytest.mark.parametrize('case', ['ordered_row_u', 'random_u', 'ties', 'descending_coarse'])
-def test_sample_fine_merge_is_the_sort(case):
+def test_sample_fine_merge_is_the_sort(case, nc, nf):
     """nerfail_sample_fine's merged row (RN:397 sort(cat(z_vals, z_samples))) is bit for bit numpy's sort of the same
     values, and pts = o + d z, through both of its branches: the binary-search merge (both halves ascending) and the rank
     sort (random u; a descending z_vals); ties between and inside the halves (zero weights: repeated samples)."""
     from nerfail_amd import _lib
     lib = _lib.load()
     rs = np.random.RandomState(4)
-    R, nc, nf = 37, 64, 128
+    R = 37
     rays = synth.ray_batch(R, seed=3)
     zc = np.sort(rs.uniform(2, 6, size=(R, nc)).astype(np.float32), -1)
     w = rs.uniform(0, 1, size=(R, nc)).astype(np.float32)
@@ -257,9 +258,9 @@ def test_sample_fine_merge_is_the_sort(case):
     if case == 'random_u':
         u, row = rs.uniform(size=(R, nf)).astype(np.float32), 0
     if case == 'ties':
-        w[:, 5:40] = 0.0                        # flat cdf stretches: many equal samples
+        w[:, nc // 12:nc * 5 // 8] = 0.0        # flat cdf stretches: many equal samples
         w[3] = 0.0                              # a ray nothing was hit on
-        zc[:, 10:14] = zc[:, 10:11]             # equal coarse depths
+        zc[:, nc // 6:nc // 6 + 3] = zc[:, nc // 6:nc // 6 + 1]     # equal coarse depths
     if case == 'descending_coarse':
         zc = zc[:, ::-1].copy()
     zs, zf = torch.empty((R, nf), device=dev()), torch.empty((R, nc + nf), device=dev())
@@ -274,7 +275,15 @@ def test_sample_fine_merge_is_the_sort(case):
     if case != 'descending_coarse':
         bins = 0.5 * (zc[:, 1:] + zc[:, :-1])
         ref = O.sample_pdf(bins, w[:, 1:-1], nf, u=None if row else u)
-        _check_samples(N(zs), ref, np.broadcast_to(u, ref.shape), bins)        # u = 1 may land one bin over (RH:239)
+        # z_samples against the oracle: equal to rounding, except where a draw sits within an ulp of a cdf entry and lands
+        # in the neighbouring bin (the cdf's last ulp differs between any two implementations of RH:205-207): rare, and by
+        # less than a bin
+        got, uu = N(zs), np.broadcast_to(u, ref.shape)
+        off = np.abs(got - ref) > 1e-5 * np.abs(ref).max()
+        assert off.mean() < 2e-3
+        assert (np.abs(got - ref)[off] <= np.diff(bins, axis=-1).max() * 1.0001).all()
+        if (nc, nf) == (64, 128):
+            _check_samples(got, ref, uu, bins)                               # u = 1 may land one bin over (RH:239)
 
 
 def test_cpu_tensors_are_moved_not_computed_on_cpu():
