@@ -713,7 +713,10 @@ def main():
     RN._mlp_points, RN._composite = orig_mlp, orig_comp
     legs = None
     if world > 1 and not args.no_attack:
-        legs = multi_gpu_legs(dev, world, rank, args.steps, (coarse, fine), K)
+        try:                                        # the extra legs must never cost the contract's JSON line
+            legs = multi_gpu_legs(dev, world, rank, args.steps, (coarse, fine), K)
+        except Exception as e:                      # (an error raised on every rank alike: nobody is left waiting in a collective)
+            legs = {'multi_gpu_legs_error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         rays_total = world * args.steps * H * W
