@@ -8,7 +8,9 @@ Each op is a `torch.library.custom_op` over ONE entry point of libnerfail_hip.so
   * `register_autograd` where the reference differentiates through the function (raw2outputs RN:262-305 -> MLP parameters,
     gauss_net's gather GN:53-119 -> the perturbation).
 `torch.library.opcheck` runs on every op in tests/test_hip_ops.py. The module-level functions of the mirrors (raw2outputs,
-create_gauss_w, igsm_step, knn8, get_rays ...) call these ops."""
+create_gauss_w, igsm_step, knn8, get_rays ...) call these ops. SURVEY's `render_rays_fused_fwd/bwd` is their composition:
+`_train.RenderRaysTrain` (a torch.autograd.Function over ray sampling, mlp_fwd_train, composite, sample_fine and, backwards,
+composite_bwd and mlp_bwd), selected by render_rays whenever a NeRF parameter requires grad."""
 import torch
 from torch import Tensor
 from torch.library import custom_op
@@ -236,5 +238,86 @@ def _(spatial, grad, spatial_init, a, epsilon, targeted):
     return torch.empty_like(spatial)
 
 
-ALL = ('ray_gen', 'composite', 'composite_bwd', 'sample_pdf', 'mlp_fwd', 'knn8', 'gauss_weight', 'gauss_gather', 'gauss_gather_bwd',
-       'igsm_step')
+# ----------------------------------------------------------------------------------------------- K6 fused fine sampling (RN:392-412)
+@custom_op(NS + '::sample_fine', mutates_args=(), device_types='cuda')
+def sample_fine(rays: Tensor, z_coarse: Tensor, weights: Tensor, u: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """sample_pdf on the mid-points (RH:200-243) + sort(cat(z_vals, z_samples)) (RN:397: SURVEY's `merge_sorted`) +
+    pts = o + d z (RN:399) + z_std (RN:412) in one launch: (z_samples [R,nf], z_fine [R,nc+nf], pts [R,nc+nf,3], z_std [R]).
+    u is [nf] (shared, perturb = 0) or [R,nf] (explicit draws)."""
+    R, nc = z_coarse.shape
+    nf = u.shape[-1]
+    dev = z_coarse.device
+    zs = torch.empty((R, nf), dtype=torch.float32, device=dev)
+    zf = torch.empty((R, nc + nf), dtype=torch.float32, device=dev)
+    pts = torch.empty((R, nc + nf, 3), dtype=torch.float32, device=dev)
+    zstd = torch.empty((R,), dtype=torch.float32, device=dev)
+    _chk(_lib.load().nerfail_sample_fine(_lib.dev(rays), R, _lib.dev(z_coarse), _lib.dev(weights), nc, _lib.dev(u), int(u.dim() == 1), nf,
+                                         _lib.dev(zs), _lib.dev(zf), _lib.dev(pts), _lib.dev(zstd), _s()))
+    return zs, zf, pts, zstd
+
+
+@sample_fine.register_fake
+def _(rays, z_coarse, weights, u):
+    R, nc = z_coarse.shape
+    nf = u.shape[-1]
+    return z_coarse.new_empty((R, nf)), z_coarse.new_empty((R, nc + nf)), z_coarse.new_empty((R, nc + nf, 3)), z_coarse.new_empty((R,))
+
+
+# ----------------------------------------------------------------------------------------------- K4b training kernels (RN:776-801)
+@custom_op(NS + '::mlp_fwd_train', mutates_args=(), device_types='cuda')
+def mlp_fwd_train(packed: Tensor, pts: Tensor, viewdirs: Tensor, D: int, W: int, skip: int) -> tuple[Tensor, Tensor]:
+    """mlp_fwd that also saves what the backward needs: (raw [R,N,4], acts [nerfail_mlp_train_acts_floats])."""
+    lib = _lib.load()
+    R, N = pts.shape[0], pts.shape[1]
+    raw = torch.empty((R, N, 4), dtype=torch.float32, device=pts.device)
+    acts = torch.empty((lib.nerfail_mlp_train_acts_floats(D, W, R * N),), dtype=torch.float32, device=pts.device)
+    _chk(lib.nerfail_mlp_fwd_train(_lib.dev(packed), D, W, skip, _lib.dev(pts), _lib.dev(viewdirs), R * N, N, _lib.dev(raw), _lib.dev(acts), _s()))
+    return raw, acts
+
+
+@mlp_fwd_train.register_fake
+def _(packed, pts, viewdirs, D, W, skip):
+    M = pts.shape[0] * pts.shape[1]
+    return pts.new_empty((pts.shape[0], pts.shape[1], 4)), pts.new_empty((_lib.load().nerfail_mlp_train_acts_floats(D, W, M),))
+
+
+def mlp_param_shapes(D, W, skip, input_ch=63, input_ch_views=27):
+    """Shapes of NeRF's parameters in _train.ordered_params order (RH:72-98): pts_linears (w, b) x D, views, feature, alpha, rgb."""
+    shapes = []
+    for i in range(D):
+        fan_in = input_ch if i == 0 else (W + input_ch if (skip >= 0 and i == skip + 1) else W)
+        shapes += [(W, fan_in), (W,)]
+    return shapes + [(W // 2, W + input_ch_views), (W // 2,), (W, W), (W,), (1, W), (1,), (3, W // 2), (3,)]
+
+
+@custom_op(NS + '::mlp_bwd', mutates_args=(), device_types='cuda')
+def mlp_bwd(packed: Tensor, packed_T: Tensor, acts: Tensor, d_raw: Tensor, D: int, W: int, skip: int) -> list[Tensor]:
+    """d loss / d (NeRF parameters) from d loss / d raw [R,N,4] and the activations mlp_fwd_train saved: backward-data pass
+    (layer gradients) + weight-gradient pass. Returns the 2 D + 8 gradients in _train.ordered_params order.
+    packed_T = _train.packed_T(net) (nerfail_mlp_pack_T)."""
+    lib = _lib.load()
+    M = d_raw.shape[0] * d_raw.shape[1]
+    dev = d_raw.device
+    dz = torch.empty((lib.nerfail_mlp_train_dz_floats(D, W, M),), dtype=torch.float32, device=dev)
+    _chk(lib.nerfail_mlp_bwd_data(_lib.dev(packed), _lib.dev(packed_T), D, W, skip, _lib.dev(d_raw), _lib.dev(acts), M, _lib.dev(dz), _s()))
+    grads = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in mlp_param_shapes(D, W, skip)]
+    mp = _lib.MlpParams()
+    mp.D, mp.W, mp.input_ch, mp.input_ch_views, mp.skip = D, W, 63, 27, skip
+    it = iter(grads)
+    for i in range(D):
+        mp.pts_w[i], mp.pts_b[i] = next(it).data_ptr(), next(it).data_ptr()
+    mp.views_w, mp.views_b = next(it).data_ptr(), next(it).data_ptr()
+    mp.feature_w, mp.feature_b = next(it).data_ptr(), next(it).data_ptr()
+    mp.alpha_w, mp.alpha_b = next(it).data_ptr(), next(it).data_ptr()
+    mp.rgb_w, mp.rgb_b = next(it).data_ptr(), next(it).data_ptr()
+    _chk(lib.nerfail_mlp_bwd_weights(D, W, skip, _lib.dev(acts), _lib.dev(dz), M, mp, _s()))
+    return grads
+
+
+@mlp_bwd.register_fake
+def _(packed, packed_T, acts, d_raw, D, W, skip):
+    return [d_raw.new_empty(sh) for sh in mlp_param_shapes(D, W, skip)]
+
+
+ALL = ('ray_gen', 'composite', 'composite_bwd', 'sample_pdf', 'sample_fine', 'mlp_fwd', 'mlp_fwd_train', 'mlp_bwd', 'knn8', 'gauss_weight',
+       'gauss_gather', 'gauss_gather_bwd', 'igsm_step')

@@ -33,12 +33,24 @@ def _samples(golden):
         'composite_bwd': (raw, T(g4['N64_z']), rays, True, ones(32, 3), ones(32), ones(32), ones(32, 64), ones(32)),
         'sample_pdf': (T(g5['bins']), T(g5['weights']), T(g5['u'])),
         'mlp_fwd': (net.packed(), pts, vd, 4, 64, -1),
+        'mlp_fwd_train': (net.packed(), pts, vd, 4, 64, -1),
+        'mlp_bwd': _mlp_bwd_args(net, pts, vd),
+        'sample_fine': (T(synth.ray_batch(32, seed=4)), T(g4['N64_z']), T(np.abs(g4['N64_raw'][..., 0]).astype(np.float32)),
+                        torch.linspace(0., 1., 24, device=dev())),
         'knn8': (Q, S),
         'gauss_weight': (T(np.stack([np.abs(rs.normal(scale=0.02, size=(1, 4, 4, 8))), rs.randint(0, 48, (1, 4, 4, 8))], 1).astype(np.float32)), 0.02),
         'gauss_gather': (T(g10['s']).requires_grad_(True), T(g10['wi']), T(g10['ori']), 32.0),
         'gauss_gather_bwd': (T(g10['wi']), T(g10['ori']), T(g10['eps32_x']), T(g10['Gx']), T(g10['Gr']), 3 * 32 * 32, 32.0),
         'igsm_step': (T(g11['s']), T(g11['grad']), T(g11['s_init']), 2.0, 32.0, False),
     }
+
+
+def _mlp_bwd_args(net, pts, vd):
+    import nerfail_amd.ops as O
+    from nerfail_amd import _train
+    raw, acts = O.mlp_fwd_train(net.packed(), pts, vd, net.D, net.W, net._skip())
+    d_raw = torch.randn_like(raw) * 1e-2
+    return (net.packed(), _train.packed_T(net), acts, d_raw, net.D, net.W, net._skip())
 
 
 def test_every_op_is_registered_and_passes_opcheck(golden):
@@ -48,7 +60,8 @@ def test_every_op_is_registered_and_passes_opcheck(golden):
     for name in O.ALL:
         op = getattr(torch.ops.nerfail_mi, name).default
         tests = ('test_schema', 'test_faketensor', 'test_autograd_registration', 'test_aot_dispatch_dynamic')
-        if name in ('gauss_gather_bwd',):           # float atomics: last bits differ run to run, which the AOT test compares
+        if name in ('gauss_gather_bwd', 'mlp_bwd', 'mlp_fwd_train'):   # float atomics (last bits differ run to run) / padding slots of
+                                                                     # `acts` that no kernel writes: the AOT test compares outputs bit for bit
             tests = ('test_schema', 'test_faketensor', 'test_autograd_registration')
         args = samples[name]
         if name == 'composite':                     # rows 0..3 have acc = 0 -> disp = NaN by the reference's semantics (RN:299);
@@ -93,3 +106,37 @@ def test_ops_trace_under_torch_compile(golden):
     eager = f(*args)
     comp = torch.compile(f, backend='aot_eager', fullgraph=True)(*args)
     assert torch.equal(eager, comp)
+
+
+def test_training_ops_match_the_autograd_function_path():
+    """torch.ops.nerfail_mi.mlp_fwd_train / mlp_bwd / sample_fine (the kernel-level halves of SURVEY 8b's nerf_mlp_fwd/bwd and
+    merge_sorted) against the path render_rays takes in training (_train.mlp_fwd_train / mlp_backward, run_nerf's fine
+    sampling): same raw bit for bit, parameter gradients equal up to the atomics' summation order."""
+    import nerfail_amd.ops as O
+    from nerfail_amd import _train
+    _, net = hip_nerf(8, 256, 5)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    rs = np.random.RandomState(2)
+    pts = T(rs.uniform(-2, 2, (40, 24, 3)).astype(np.float32))
+    vd = T(rs.normal(size=(40, 3)).astype(np.float32))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    raw_a, acts_a = _train.mlp_fwd_train(net, pts, vd)
+    raw_b, acts_b = O.mlp_fwd_train(net.packed(), pts, vd, net.D, net.W, net._skip())
+    assert torch.equal(raw_a, raw_b)                    # (`acts` has padding slots no kernel writes: compared through the gradients)
+    d_raw = T((rs.normal(size=(40, 24, 4)) * 1e-2).astype(np.float32))
+    ga = _train._zero_grads(net)
+    _train.mlp_backward(net, d_raw, acts_a, ga)
+    gb = O.mlp_bwd(net.packed(), _train.packed_T(net), acts_b, d_raw, net.D, net.W, net._skip())
+    assert len(ga) == len(gb) == 2 * net.D + 8
+    for a, b, p in zip(ga, gb, _train.ordered_params(net)):
+        assert tuple(b.shape) == tuple(p.shape)
+        assert rel_err(N(b), N(a)) < 1e-4
+    # sample_fine: the sorted row really is the sort, z_std the (biased) std of the new samples
+    rays = T(synth.ray_batch(40, seed=6))
+    zc = torch.sort(torch.rand((40, 64), device=dev()) * 4 + 2, -1)[0]
+    w = torch.rand((40, 64), device=dev())
+    zs, zf, pts_f, zstd = O.sample_fine(rays, zc, w, torch.linspace(0., 1., 128, device=dev()))
+    assert torch.equal(zf, torch.sort(torch.cat([zc, zs], -1), -1)[0])
+    assert rel_err(N(zstd), N(zs.std(-1, unbiased=False))) < 1e-4
+    assert torch.equal(pts_f, rays[:, None, 3:6] * zf[..., None] + rays[:, None, 0:3])
