@@ -328,3 +328,25 @@ def test_backward_with_an_all_background_view_and_ragged_chunks(golden):
         return s.grad
     a, b, ref = grad(True), grad(True), grad(False)
     assert torch.equal(a, b) and rel_err(N(a), N(ref)) < 1e-4
+
+
+def test_backward_of_more_views_than_one_launch_holds():
+    """nerfail_gauss_bwd_views reduces up to 16 views per launch; a batch of 19 takes two rounds, the second accumulating
+    onto the first (fixed order: bitwise repeatable; equal to the float-atomic form to rounding)."""
+    from nerfail_amd import GaussNet as G
+    rs = np.random.RandomState(12)
+    B, P, H, W = 19, 3, 12, 10
+    s0 = T(rs.uniform(-40, 40, size=(P, H, W, 4)).astype(np.float32))
+    ori = T(synth.disc_alpha_image(B, H, W, seed=13))
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    idx = rs.randint(0, P * H * W, size=(B, H, W, 8)).astype(np.float32)
+    wi, _ = G.create_gauss_w(dev(), 0.02)(T(np.stack([dist, idx], 1)))
+    Gr = T(rs.normal(size=(B, H, W, 4)).astype(np.float32))
+
+    def grad(det):
+        s = s0.clone().requires_grad_(True)
+        x, xr = G.gauss_gather(s, wi, ori, 24.0, None, det)
+        ((xr * Gr).sum() + x.sum()).backward()
+        return s.grad
+    a, b, ref = grad(True), grad(True), grad(False)
+    assert torch.equal(a, b) and rel_err(N(a), N(ref)) < 1e-4
