@@ -21,12 +21,12 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, retraw=False
                            want_pts_max=True, **extra)
 
 
-def batchify_rays(rays_flat, chunk=1024 * 16, **kwargs):
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
     """NC:55-67."""
     return _rn.batchify_rays(rays_flat, chunk, want_pts_max=True, **kwargs)
 
 
-def render(H, W, K, chunk=1024 * 16, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
            c2w_staticcam=None, **kwargs):
     """NC:70-135 -> [rgb_map, disp_map, acc_map, pts_max, extras]."""
     return _rn._render(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, True, kwargs)

@@ -696,8 +696,80 @@ def g17():
          exact64_dist=np.take_along_axis(d64, order, -1))
 
 
+# ---------------------------------------------------------------- G18 load_blender_data (load_blender.py:37-110)
+def g18():
+    """The reference's Blender loader RUN on a toy scene on disk (Blender-synthetic layout, written by
+    tests/test_load_blender.py::write_toy_scene), plain, with testskip and with the NeRFail `train_dir` override.
+    `imageio` is absent here: its imread is backed by PIL for this call (PNG decoding is lossless, so every decoder
+    returns the same uint8 array). `half_res` needs cv2.resize (absent; a stub would be a stand-in for the library):
+    NOT pinned by this fixture - the mirror's half_res stays covered by the 2x2-block-mean property test."""
+    import tempfile
+    from PIL import Image
+    from test_load_blender import write_toy_scene
+    sys.modules['imageio'].imread = lambda path: np.asarray(Image.open(path))
+    import load_blender as LB  # noqa: E402  (reference)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, 'toy')
+        raw = write_toy_scene(root, H=12, W=12, n=(3, 2, 2), seed=18)
+        for split in ('train', 'val', 'test'):
+            out['raw_' + split] = raw[split]
+            out['json_' + split] = np.frombuffer(open(os.path.join(root, 'transforms_%s.json' % split), 'rb').read(), np.uint8)
+        adv = os.path.join(tmp, 'adv')
+        os.makedirs(adv)
+        adv_raw = 255 - raw['train']
+        adv_raw[..., 3] = raw['train'][..., 3]
+        for i in range(adv_raw.shape[0]):
+            Image.fromarray(adv_raw[i], 'RGBA').save(os.path.join(adv, 'r_%d.png' % i))
+        out['raw_adv'] = adv_raw
+        imgs, poses, render_poses, hwf, i_split = LB.load_blender_data(root, half_res=False, testskip=1)
+        out.update(plain_imgs=imgs, plain_poses=poses, plain_render_poses=render_poses.numpy(),
+                   plain_hwf=np.array(hwf, np.float64), plain_i_split=np.concatenate(i_split),
+                   plain_i_split_sizes=np.array([len(s) for s in i_split]))
+        imgs2, poses2, _, hwf2, i_split2 = LB.load_blender_data(root, half_res=False, testskip=2)
+        out.update(skip2_imgs=imgs2, skip2_poses=poses2, skip2_i_split_sizes=np.array([len(s) for s in i_split2]))
+        (t_imgs, rest), poses3, rp3, hwf3, i_split3 = LB.load_blender_data(root, train_dir=adv)
+        out.update(adv_train_imgs=t_imgs, adv_rest_imgs=rest, adv_poses=poses3, adv_render_poses=rp3.numpy(),
+                   adv_hwf=np.array(hwf3, np.float64), adv_i_split=np.concatenate(i_split3),
+                   adv_i_split_sizes=np.array([len(s) for s in i_split3]))
+        out['pose_spherical_37_m30_4'] = LB.pose_spherical(37.0, -30.0, 4.0).numpy()
+    save('g18_load_blender', **out)
+
+
+# ---------------------------------------------------------------- G19 call signatures of the boundary (SURVEY.md 8b)
+def g19():
+    """Parameter names, kinds and defaults (repr) of the reference functions the mirror keeps drop-in compatible; data
+    only (inspect.signature), stored as JSON so that the CPU suite can diff the mirror's signatures against them."""
+    import inspect
+    import json
+    import deepfool as DF  # noqa: E402  (reference)
+    sys.modules['imageio'].imread = getattr(sys.modules['imageio'], 'imread', None)
+    import load_blender as LB  # noqa: E402  (reference)
+
+    def sig(fn):
+        return [[p.name, str(p.kind), None if p.default is inspect.Parameter.empty else repr(p.default)]
+                for p in inspect.signature(fn).parameters.values()]
+    table = {
+        'run_nerf.render': sig(RN.render), 'run_nerf.batchify_rays': sig(RN.batchify_rays), 'run_nerf.render_rays': sig(RN.render_rays),
+        'run_nerf.raw2outputs': sig(RN.raw2outputs), 'run_nerf.run_network': sig(RN.run_network), 'run_nerf.batchify': sig(RN.batchify),
+        'run_nerf.render_path': sig(RN.render_path), 'run_nerf.create_nerf': sig(RN.create_nerf),
+        'run_nerf_helpers.get_rays': sig(RH.get_rays), 'run_nerf_helpers.get_rays_np': sig(RH.get_rays_np),
+        'run_nerf_helpers.sample_pdf': sig(RH.sample_pdf), 'run_nerf_helpers.get_embedder': sig(RH.get_embedder),
+        'run_nerf_helpers.NeRF.__init__': sig(RH.NeRF.__init__), 'run_nerf_helpers.NeRF.forward': sig(RH.NeRF.forward),
+        'nerf_to_coord.render': sig(NC.render), 'nerf_to_coord.batchify_rays': sig(NC.batchify_rays),
+        'nerf_to_coord.render_rays': sig(NC.render_rays), 'nerf_to_coord.render_path': sig(NC.render_path),
+        'GaussNet.gauss_net.__init__': sig(GN.gauss_net.__init__), 'GaussNet.gauss_net.forward': sig(GN.gauss_net.forward),
+        'GaussNet.create_gauss_w.__init__': sig(GN.create_gauss_w.__init__), 'GaussNet.create_gauss_w.forward': sig(GN.create_gauss_w.forward),
+        'deepfool.deepfool': sig(DF.deepfool), 'load_blender.load_blender_data': sig(LB.load_blender_data),
+        'load_blender.pose_spherical': sig(LB.pose_spherical),
+    }
+    path = os.path.join(HERE, 'g19_signatures.json')
+    json.dump(table, open(path, 'w'), indent=1, sort_keys=True)
+    print('%-28s %8.1f KB' % ('g19_signatures.json', os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19']
     for w in which:
         globals()[w]()
 

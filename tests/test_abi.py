@@ -89,3 +89,25 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_mirror_signatures_match_reference():
+    """Fixture g19 = inspect.signature of the reference's boundary functions (tests/golden/make_golden.py, reference imported
+    there). Every mirror must start with exactly the reference's parameters (names, kinds, defaults); what a mirror adds
+    (explicit random draws, view ids) must come AFTER them and be optional, so reference call sites keep working."""
+    import inspect
+    import json
+    from nerfail_amd import run_nerf, run_nerf_helpers, nerf_to_coord, GaussNet, deepfool, load_blender
+    mods = {'run_nerf': run_nerf, 'run_nerf_helpers': run_nerf_helpers, 'nerf_to_coord': nerf_to_coord, 'GaussNet': GaussNet,
+            'deepfool': deepfool, 'load_blender': load_blender}
+    table = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'g19_signatures.json')))
+    assert len(table) >= 25
+    for name, ref in sorted(table.items()):
+        obj = mods[name.split('.')[0]]
+        for part in name.split('.')[1:]:
+            obj = getattr(obj, part)
+        mine = [[p.name, str(p.kind), None if p.default is inspect.Parameter.empty else repr(p.default)]
+                for p in inspect.signature(obj).parameters.values()]
+        assert mine[:len(ref)] == ref, (name, ref, mine)
+        for extra in mine[len(ref):]:
+            assert extra[2] is not None or extra[1] in ('VAR_KEYWORD', 'VAR_POSITIONAL'), (name, extra)

@@ -1,5 +1,7 @@
 """CPU: the Blender loader mirror (load_blender.py:37-110) on a toy scene written in the dataset's own format, with and
-without the NeRFail `train_dir` override, against expectations derived from the files themselves."""
+without the NeRFail `train_dir` override: (i) against what the REFERENCE's load_blender_data returned for the same files
+(fixture g18, tests/golden/make_golden.py), every array compared exactly; (ii) against expectations derived from the
+files themselves (incl. half_res, which the fixture cannot pin: the reference needs cv2.resize, absent in the container)."""
 import json
 import os
 
@@ -69,3 +71,40 @@ def test_load_blender_data_plain_and_train_dir(tmp_path):
     assert training_images(imgs, white_bkgd=False).shape == (7, 12, 12, 3)
     with pytest.raises(FileNotFoundError):
         load_blender_data(root, train_dir=str(tmp_path / 'missing'))
+
+
+def test_load_blender_matches_reference_fixture(tmp_path):
+    """g18: the reference's load_blender_data was RUN on this very scene (files rebuilt here from the fixture's raw uint8
+    images and JSON texts; PNG is lossless). Every returned array must be equal, dtype included."""
+    from PIL import Image
+    from nerfail_amd.load_blender import load_blender_data, pose_spherical
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g18_load_blender.npz'))
+    root = str(tmp_path / 'toy')
+    for split in ('train', 'val', 'test'):
+        os.makedirs(os.path.join(root, split))
+        open(os.path.join(root, 'transforms_%s.json' % split), 'wb').write(g['json_' + split].tobytes())
+        for i, img in enumerate(g['raw_' + split]):
+            Image.fromarray(img, 'RGBA').save(os.path.join(root, split, 'r_%d.png' % i))
+    adv = str(tmp_path / 'adv')
+    os.makedirs(adv)
+    for i, img in enumerate(g['raw_adv']):
+        Image.fromarray(img, 'RGBA').save(os.path.join(adv, 'r_%d.png' % i))
+
+    def same(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), (a.dtype, b.dtype, a.shape, b.shape)
+
+    imgs, poses, render_poses, hwf, i_split = load_blender_data(root, half_res=False, testskip=1)
+    same(imgs, g['plain_imgs']); same(poses, g['plain_poses']); same(render_poses.numpy(), g['plain_render_poses'])
+    same(np.array(hwf, np.float64), g['plain_hwf']); same(np.concatenate(i_split), g['plain_i_split'])
+    assert [len(s) for s in i_split] == list(g['plain_i_split_sizes'])
+    assert isinstance(hwf[0], int) and isinstance(hwf[1], int)
+    imgs2, poses2, _, _, i_split2 = load_blender_data(root, half_res=False, testskip=2)
+    same(imgs2, g['skip2_imgs']); same(poses2, g['skip2_poses'])
+    assert [len(s) for s in i_split2] == list(g['skip2_i_split_sizes'])
+    (t_imgs, rest), poses3, rp3, hwf3, i_split3 = load_blender_data(root, train_dir=adv)
+    same(t_imgs, g['adv_train_imgs']); same(rest, g['adv_rest_imgs']); same(poses3, g['adv_poses'])
+    same(rp3.numpy(), g['adv_render_poses']); same(np.array(hwf3, np.float64), g['adv_hwf'])
+    same(np.concatenate(i_split3), g['adv_i_split'])
+    assert [len(s) for s in i_split3] == list(g['adv_i_split_sizes'])
+    same(pose_spherical(37.0, -30.0, 4.0).numpy(), g['pose_spherical_37_m30_4'])
