@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NERFAIL_ABI_VERSION 3
+#define NERFAIL_ABI_VERSION 4
 
 #define NERFAIL_OK 0
 #define NERFAIL_EINVAL 1   /* bad argument (null pointer, size, unsupported shape) */
@@ -160,18 +160,33 @@ int nerfail_mlp_fwd_train(const float* packed, int D, int W, int skip, const flo
 /* Transposed weight image for the backward-data pass (re-pack after every optimizer step). */
 size_t nerfail_mlp_packed_T_floats(int D, int W, int skip);
 int nerfail_mlp_pack_T(const nerfail_mlp_params* params_host, float* packedT, void* stream);
+/* nerfail_mlp_pack + nerfail_mlp_pack_T in ONE launch (the training loop re-packs both after every optimizer step). */
+int nerfail_mlp_pack_train(const nerfail_mlp_params* params_host, float* packed, float* packedT, void* stream);
 /* d_raw[M,4] -> gradient w.r.t. every layer's pre-activation (`dz`, fragment layout). */
 int nerfail_mlp_bwd_data(const float* packed, const float* packedT, int D, int W, int skip, const float* d_raw,
                          const float* acts, int64_t M, float* dz, void* stream);
-/* Parameter gradients: grads_host holds DEVICE pointers shaped like the nn.Linear tensors (same struct as the
- * weights); every gradient is ACCUMULATED into (+=, float atomics), so zero them for a fresh gradient. */
-int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
-                            const nerfail_mlp_params* grads_host, void* stream);
-
-/* Same with the operands converted in registers to bf16 hi/lo pairs and 3 bf16 MFMAs per product block (fp32
- * accumulation, fp32 exponent range, ~1.5e-5 relative per product: a gradient-grade opt-in mode). */
-int nerfail_mlp_bwd_weights_bf16x3(int D, int W, int skip, const float* acts, const float* dz, int64_t M,
-                                   const nerfail_mlp_params* grads_host, void* stream);
+/* The same for TWO networks of one architecture in ONE launch (the coarse and the fine network of a training step:
+ * independent, RN:394): d_raw / acts / dz hold the M0 samples (tiles) of network 0 followed by the M1 of network 1;
+ * M0 must be a multiple of 32 when M1 > 0. */
+int nerfail_mlp_bwd_data2(const float* packed0, const float* packedT0, int64_t M0, const float* packed1,
+                          const float* packedT1, int64_t M1, int D, int W, int skip, const float* d_raw,
+                          const float* acts, float* dz, void* stream);
+/* Parameter gradients of ONE or TWO networks of the same architecture in one launch (RN:791; the coarse and the
+ * fine network of a training step are independent because RN:394 detaches z_samples). `acts` / `dz` hold the tiles
+ * of network 0 (M0 samples) followed by those of network 1 (M1 samples; M1 = 0: one network, then M0 need not be a
+ * multiple of 32). gradsN hold DEVICE pointers shaped like the nn.Linear tensors (same struct as the weights).
+ * flags: NERFAIL_DW_ACCUMULATE adds to the gradient tensors (+=), otherwise they are overwritten;
+ *        NERFAIL_DW_BF16X3 converts the operands in registers to bf16 hi/lo pairs, 3 bf16 MFMAs per product block
+ *        (fp32 accumulation, fp32 exponent range, ~1.5e-5 relative per product: a gradient-grade opt-in mode).
+ * W = 256: LDS-staged kernel, NO float atomics - every workgroup writes its partial block to `scratch`
+ * (nerfail_mlp_bwd_weights_scratch_bytes) and a second kernel adds the partials in workgroup order, so the result is
+ * bitwise reproducible. Other widths (and NERFAIL_DW_KERNEL=reg): register-fed kernel with float atomics, no scratch. */
+#define NERFAIL_DW_BF16X3 1
+#define NERFAIL_DW_ACCUMULATE 2
+size_t nerfail_mlp_bwd_weights_scratch_bytes(int D, int W, int skip, int64_t M0, int64_t M1, int flags);
+int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts, const float* dz, int64_t M0,
+                            const nerfail_mlp_params* grads0, int64_t M1, const nerfail_mlp_params* grads1, int flags,
+                            void* scratch, size_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------ compositing (K5, K7) -- */
 

@@ -11,8 +11,9 @@ import torch  # noqa: F401  (must be imported first: libnerfail_hip.so binds to 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFAIL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerfail_hip.so')   # override: A/B builds (tools/ablate.py)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DEPTH = 16
+DW_BF16X3, DW_ACCUMULATE = 1, 2          # flags of nerfail_mlp_bwd_weights
 RAY_FLOATS = 11
 
 c_f = ctypes.c_float
@@ -63,9 +64,12 @@ SIGNATURES = {
     'nerfail_mlp_fwd_train': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
     'nerfail_mlp_packed_T_floats': (ctypes.c_size_t, [c_i, c_i, c_i]),
     'nerfail_mlp_pack_T': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
+    'nerfail_mlp_pack_train': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p, c_p]),
     'nerfail_mlp_bwd_data': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_p, c_p]),
-    'nerfail_mlp_bwd_weights': (c_i, [c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.POINTER(MlpParams), c_p]),
-    'nerfail_mlp_bwd_weights_bf16x3': (c_i, [c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.POINTER(MlpParams), c_p]),
+    'nerfail_mlp_bwd_data2': (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'nerfail_mlp_bwd_weights_scratch_bytes': (ctypes.c_size_t, [c_i, c_i, c_i, c_i64, c_i64, c_i]),
+    'nerfail_mlp_bwd_weights': (c_i, [c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.POINTER(MlpParams), c_i64, ctypes.POINTER(MlpParams),
+                                      c_i, c_p, ctypes.c_size_t, c_p]),
     'nerfail_composite': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_composite_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_knn8': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),

@@ -119,6 +119,82 @@ __global__ void pack_heads_kernel(const float* __restrict__ aw, const float* __r
     }
 }
 
+// Training re-packs BOTH images (forward + transposed) after every optimizer step: 1 + 1 + (D + 1) launches of ~5 us each
+// per network were 1.3 % of a training step. One launch instead: blockIdx.y walks the forward layers, then the heads,
+// then the transposed layers ([quad][in-tile t][lane (i = l&31 -> input channel 32t+i, h = l>>5)][e]:
+// W[o = out channel of k-step 4q+e in half h][col0 + 32t + i], as pack_layer_T_kernel in mlp_bwd.hip).
+struct PackTDesc { const float* w; int out_f, in_f, col0, total; unsigned off; };
+struct PackTrainTable {
+    PackTable fwd;
+    int nT, W;
+    const float* aw; const float* ab; const float* rw; const float* rb;
+    unsigned alpha_off, rgb_off;
+    PackTDesc t[NERFAIL_MAX_DEPTH + 2];
+};
+__global__ void pack_train_kernel(PackTrainTable t, float* __restrict__ packed, float* __restrict__ packedT) {
+    const int job = blockIdx.y, NT = t.fwd.NT;
+    const int stride = gridDim.x * blockDim.x, g0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job < t.fwd.n) {
+        const PackLayerDesc& d = t.fwd.l[job];
+        const int n = d.total_w > d.OT * 32 ? d.total_w : d.OT * 32;
+        for (int g = g0; g < n; g += stride) {
+            if (g < d.OT * 32) {
+                const int tt = g / 32, hh = (g / 16) & 1, r = g & 15;
+                const int ch = 32 * tt + acc_channel(r, hh);
+                packed[d.b_off + g] = (ch < d.out_f) ? d.b[ch] : 0.f;
+            }
+            if (g >= d.total_w) continue;
+            const int e = g & 3, lane = (g >> 2) & 63, rest = g >> 8;
+            const int tt = rest % d.OT;
+            int q = rest / d.OT;
+            const int hh = lane >> 5, row = 32 * tt + (lane & 31);
+            int col = -1;
+            if (d.emb0 >= 0) {
+                if (q < kEmbQuads) { const int c = enc_channel(4 * q + e, hh, 10); col = c < 0 ? -1 : d.emb0 + c; q = -1; }
+                else q -= kEmbQuads;
+            }
+            if (q >= 0 && d.h0 >= 0) {
+                if (q < NT * 4) { const int s_ = 4 * q + e; col = d.h0 + 32 * (s_ / 16) + acc_channel(s_ % 16, hh); q = -1; }
+                else q -= NT * 4;
+            }
+            if (q >= 0 && d.dir0 >= 0) {
+                const int c = enc_channel(4 * q + e, hh, 4); col = c < 0 ? -1 : d.dir0 + c;
+            }
+            packed[d.w_off + g] = (row < d.out_f && col >= 0) ? d.w[(long)row * d.in_f + col] : 0.f;
+        }
+    } else if (job == t.fwd.n) {
+        const int W = t.W, OTV = NT / 2;
+        float* __restrict__ aq = packed + t.alpha_off;
+        float* __restrict__ rq = packed + t.rgb_off;
+        for (int g = g0; g < NT * 32 + 4 || g < 3 * OTV * 32 + 4; g += stride) {
+            if (g < NT * 32) {
+                const int tt = g / 32, hh = (g / 16) & 1, r = g & 15;
+                aq[g] = t.aw[32 * tt + acc_channel(r, hh)];
+            } else if (g < NT * 32 + 4) {
+                aq[g] = (g == NT * 32) ? t.ab[0] : 0.f;
+            }
+            if (g < 3 * OTV * 32) {
+                const int c = g / (OTV * 32), rem = g % (OTV * 32);
+                const int tt = rem / 32, hh = (rem / 16) & 1, r = rem & 15;
+                rq[g] = t.rw[c * (W / 2) + 32 * tt + acc_channel(r, hh)];
+            } else if (g < 3 * OTV * 32 + 4) {
+                const int c = g - 3 * OTV * 32;
+                rq[g] = (c < 3) ? t.rb[c] : 0.f;
+            }
+        }
+    } else {
+        const PackTDesc& d = t.t[job - t.fwd.n - 1];
+        for (int g = g0; g < d.total; g += stride) {
+            const int e = g & 3, lane = (g >> 2) & 63, rest = g >> 8;
+            const int tt = rest % NT, q = rest / NT;
+            const int s_ = 4 * q + e, hh = lane >> 5;
+            const int o = 32 * (s_ / 16) + acc_channel(s_ % 16, hh);
+            const int i = 32 * tt + (lane & 31);
+            packedT[d.off + g] = (o < d.out_f) ? d.w[(long)o * d.in_f + d.col0 + i] : 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- device side
 template <int NT, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
@@ -331,17 +407,13 @@ extern "C" size_t nerfail_mlp_packed_floats(int D, int W, int skip) {
     return make_layout(D, W, skip, L) ? (size_t)L.total : 0;
 }
 
-extern "C" int nerfail_mlp_pack(const nerfail_mlp_params* p, float* packed, void* stream) {
-    NF_REQUIRE(p != nullptr && packed != nullptr, "NULL pointer");
+static int fill_pack_table(const nerfail_mlp_params* p, MlpLayout& L, PackTable& tab) {
     NF_REQUIRE(p->input_ch == kPtsCh && p->input_ch_views == kDirCh, "only multires=10 / multires_views=4 (63 + 27 channels)");
-    MlpLayout L;
     NF_REQUIRE(make_layout(p->D, p->W, p->skip, L), "unsupported (D, W): W in {64,128,256}, 2 <= D <= 16");
     for (int i = 0; i < p->D; ++i) NF_REQUIRE(p->pts_w[i] != nullptr && p->pts_b[i] != nullptr, "pts_linears pointer is NULL");
     NF_REQUIRE(p->views_w && p->views_b && p->feature_w && p->feature_b && p->alpha_w && p->alpha_b && p->rgb_w && p->rgb_b,
                "head pointer is NULL");
-    hipStream_t s = as_stream(stream);
     const int W = p->W, NT = L.NT, OTV = NT / 2;
-    PackTable tab;
     tab.n = p->D + 2; tab.NT = NT;
     for (int l = 0; l <= p->D + 1; ++l) {
         const bool emb = l <= p->D - 1 && layer_has_emb(l, L.skip);
@@ -360,12 +432,53 @@ extern "C" int nerfail_mlp_pack(const nerfail_mlp_params* p, float* packed, void
         d.total_w = (int)L.w_count[l];
         d.w_off = L.w_off[l]; d.b_off = L.b_off[l];
     }
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_mlp_pack(const nerfail_mlp_params* p, float* packed, void* stream) {
+    NF_REQUIRE(p != nullptr && packed != nullptr, "NULL pointer");
+    MlpLayout L;
+    PackTable tab;
+    const int rc = fill_pack_table(p, L, tab);
+    if (rc != NERFAIL_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    const int W = p->W, NT = L.NT, OTV = NT / 2;
     pack_all_layers_kernel<<<dim3(64, (unsigned)tab.n), dim3(256), 0, s>>>(tab, packed);
     NF_LAUNCHED("pack_all_layers_kernel");
     const int nh = (NT * 32 + 4) > (3 * OTV * 32 + 4) ? (NT * 32 + 4) : (3 * OTV * 32 + 4);
     pack_heads_kernel<<<dim3((nh + 255) / 256), dim3(256), 0, s>>>(p->alpha_w, p->alpha_b, p->rgb_w, p->rgb_b, W,
                                                                   packed + L.alpha_off, packed + L.rgb_off);
     NF_LAUNCHED("pack_heads_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_mlp_pack_train(const nerfail_mlp_params* p, float* packed, float* packedT, void* stream) {
+    NF_REQUIRE(p != nullptr && packed != nullptr && packedT != nullptr, "NULL pointer");
+    MlpLayout L;
+    PackTrainTable t;
+    const int rc = fill_pack_table(p, L, t.fwd);
+    if (rc != NERFAIL_OK) return rc;
+    MlpLayoutT T;
+    make_layout_T(p->D, L.NT, T);
+    const int W = p->W, NT = L.NT;
+    t.W = W; t.aw = p->alpha_w; t.ab = p->alpha_b; t.rw = p->rgb_w; t.rb = p->rgb_b;
+    t.alpha_off = L.alpha_off; t.rgb_off = L.rgb_off;
+    t.nT = 0;
+    for (int l = 1; l <= p->D + 1; ++l) {
+        PackTDesc& d = t.t[t.nT++];
+        if (l < p->D) {
+            const bool emb = layer_has_emb(l, L.skip);
+            d.w = p->pts_w[l]; d.out_f = W; d.in_f = emb ? W + kPtsCh : W; d.col0 = emb ? kPtsCh : 0;
+        } else if (l == p->D) {
+            d.w = p->feature_w; d.out_f = W; d.in_f = W; d.col0 = 0;
+        } else {
+            d.w = p->views_w; d.out_f = W / 2; d.in_f = W + kDirCh; d.col0 = 0;
+        }
+        d.total = (int)(((l == p->D + 1) ? (NT / 2) * 4 : NT * 4) * NT * 256);
+        d.off = T.w_off[l];
+    }
+    pack_train_kernel<<<dim3(32, (unsigned)(t.fwd.n + 1 + t.nT)), dim3(256), 0, as_stream(stream)>>>(t, packed, packedT);
+    NF_LAUNCHED("pack_train_kernel");
     return NERFAIL_OK;
 }
 

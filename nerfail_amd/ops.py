@@ -300,7 +300,7 @@ def mlp_bwd(packed: Tensor, packed_T: Tensor, acts: Tensor, d_raw: Tensor, D: in
     dev = d_raw.device
     dz = torch.empty((lib.nerfail_mlp_train_dz_floats(D, W, M),), dtype=torch.float32, device=dev)
     _chk(lib.nerfail_mlp_bwd_data(_lib.dev(packed), _lib.dev(packed_T), D, W, skip, _lib.dev(d_raw), _lib.dev(acts), M, _lib.dev(dz), _s()))
-    grads = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in mlp_param_shapes(D, W, skip)]
+    grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in mlp_param_shapes(D, W, skip)]     # overwritten
     mp = _lib.MlpParams()
     mp.D, mp.W, mp.input_ch, mp.input_ch_views, mp.skip = D, W, 63, 27, skip
     it = iter(grads)
@@ -310,7 +310,9 @@ def mlp_bwd(packed: Tensor, packed_T: Tensor, acts: Tensor, d_raw: Tensor, D: in
     mp.feature_w, mp.feature_b = next(it).data_ptr(), next(it).data_ptr()
     mp.alpha_w, mp.alpha_b = next(it).data_ptr(), next(it).data_ptr()
     mp.rgb_w, mp.rgb_b = next(it).data_ptr(), next(it).data_ptr()
-    _chk(lib.nerfail_mlp_bwd_weights(D, W, skip, _lib.dev(acts), _lib.dev(dz), M, mp, _s()))
+    nbytes = lib.nerfail_mlp_bwd_weights_scratch_bytes(D, W, skip, M, 0, 0)
+    scratch = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)      # per-workgroup partials (deterministic sum)
+    _chk(lib.nerfail_mlp_bwd_weights(D, W, skip, _lib.dev(acts), _lib.dev(dz), M, mp, 0, None, 0, _lib.dev(scratch), nbytes, _s()))
     return grads
 
 

@@ -338,8 +338,19 @@ def _render_rays_pipeline(rays, network_fn, network_fine, user_query, N_samples,
             return _lib.f32c(user_query(p, viewdirs, fn), dev), None   # user-supplied query function (reference contract)
         if train:
             from . import _train
-            return _train.mlp_fwd_train(fn, p, viewdirs)
+            return _train.mlp_fwd_train(fn, p, viewdirs, acts=acts_for.pop(0) if acts_for else None)
         return _mlp_points(fn, p, viewdirs), None                      # fused encode + MLP, nothing materialised
+
+    # training: the saved activations of the coarse and the fine pass share ONE buffer (coarse tiles first), so that the
+    # backward walks both networks in one launch per kernel
+    acts_all, acts_for = None, []
+    if train and user_query is None and N_importance > 0:
+        from . import _train
+        run_fn_ = network_fn if network_fine is None else network_fine
+        if _train._same_arch(network_fn, run_fn_) and (R * N_samples) % 32 == 0:
+            nc, nf = _train.acts_floats(network_fn, R * N_samples), _train.acts_floats(run_fn_, R * (N_samples + N_importance))
+            acts_all = torch.empty((nc + nf,), dtype=torch.float32, device=dev)
+            acts_for = [acts_all[:nc], acts_all[nc:]]
 
     z_vals = torch.empty((R, N_samples), dtype=torch.float32, device=dev)
     pts = torch.empty((R, N_samples, 3), dtype=torch.float32, device=dev)
@@ -350,7 +361,7 @@ def _render_rays_pipeline(rays, network_fn, network_fine, user_query, N_samples,
     rgb_map, disp_map, acc_map, weights, depth_map, pts_max = _composite(
         raw, z_vals, rays, nz, white_bkgd, pts if (want_pts_max and last_pass) else None)
     out = {'rgb0': empty(), 'disp0': empty(), 'acc0': empty(), 'z_std': empty()}
-    saved = {'rays': rays, 'coarse': dict(raw=raw, z=z_vals, acts=acts, noise=nz), 'fine': None}
+    saved = {'rays': rays, 'coarse': dict(raw=raw, z=z_vals, acts=acts, noise=nz), 'fine': None, 'acts_all': acts_all}
     if N_importance > 0:
         out.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
         Nt = N_samples + N_importance

@@ -67,7 +67,9 @@ def hip_mlp_grads(net, pts, dirs, d_raw, fwd='f32', bd='f32', dw='f32'):
     else:
         _lib.check(lib.nerfail_mlp_bwd_data(_lib.dev(net.packed()), _lib.dev(_train.packed_T(net)), net.D, net.W,
                                             net._skip(), _lib.dev(d_raw), _lib.dev(acts), M, _lib.dev(dz), _lib.stream()))
-    fn = lib.nerfail_mlp_bwd_weights_bf16x3 if dw == 'split' else lib.nerfail_mlp_bwd_weights
-    _lib.check(fn(net.D, net.W, net._skip(), _lib.dev(acts), _lib.dev(dz), M, _train._grads_struct(net, g), _lib.stream()))
+    flags = (_lib.DW_BF16X3 if dw == 'split' else 0) | _lib.DW_ACCUMULATE
+    scratch, nbytes = _train.dw_scratch(net, M, 0, flags, d_raw.device)
+    _lib.check(lib.nerfail_mlp_bwd_weights(net.D, net.W, net._skip(), _lib.dev(acts), _lib.dev(dz), M, _train._grads_struct(net, g), 0, None,
+                                           flags, _lib.dev(scratch), nbytes, _lib.stream()))
     byp = {id(p): n for n, p in net.named_parameters()}
     return {byp[id(p)]: t.double().cpu().numpy() for p, t in zip(_train.ordered_params(net), g)}

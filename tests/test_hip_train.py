@@ -192,3 +192,59 @@ def test_mlp_backward_on_identical_inputs(golden, dw_kernel, monkeypatch):
     print('\n'.join(lines))
     print('HIP f32 backward (%s) vs reference autograd on identical inputs: worst error / bound = %.2f' % (dw_kernel, worst))
     assert worst <= 1.0, '\n'.join(lines)
+
+
+def _step_grads(coarse, fine, rays, target, t_rand, u):
+    from nerfail_amd import run_nerf as RN
+    for p in list(coarse.parameters()) + list(fine.parameters()):
+        p.grad = None
+    r = RN.render_rays(T(rays), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.,
+                       t_rand=T(t_rand), u=T(u))
+    loss = RN.img2mse(r['rgb_map'], T(target)) + RN.img2mse(r['rgb0'], T(target))
+    loss.backward()
+    return {('c' if n is coarse else 'f') + k: p.grad.clone() for n in (coarse, fine) for k, p in n.named_parameters()}
+
+
+def test_training_step_is_bitwise_reproducible(golden):
+    """the W = 256 weight gradients carry no float atomics (per-workgroup partial slabs, summed in
+    workgroup order), so two runs of the same step give the SAME BITS in every parameter gradient."""
+    g = golden('g7_train_grads')
+    _, coarse = hip_nerf(8, 256, 31, requires_grad=True)
+    _, fine = hip_nerf(8, 256, 32, requires_grad=True)
+    args = (g['full_rays'], g['full_target'], g['full_t_rand'], g['full_u'])
+    a = _step_grads(coarse, fine, *args)
+    for rep in range(3):
+        b = _step_grads(coarse, fine, *args)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (rep, k)
+
+
+def test_joint_backward_equals_separate_launches(golden):
+    """The coarse and the fine network's backward run as ONE launch per kernel (nerfail_mlp_bwd_data2, two-network
+    nerfail_mlp_bwd_weights): same gradients as one launch per network (different partition -> last-bit differences
+    only), and a network evaluated for both passes (network_fine=None) accumulates both."""
+    from nerfail_amd import _train, _lib
+    rs = np.random.RandomState(5)
+    _, n0 = hip_nerf(8, 256, 41, requires_grad=True)
+    _, n1 = hip_nerf(8, 256, 42, requires_grad=True)
+    R, Nc, Nf = 96, 64, 192
+    M0, M1 = R * Nc, R * Nf
+    pts = T(rs.uniform(-2, 2, (R, Nc + Nf, 3)).astype(np.float32))
+    vd = T(synth.ray_batch(R, seed=3)[:, 8:11].copy())
+    nA = _train.acts_floats(n0, M0)
+    acts = torch.empty((nA + _train.acts_floats(n1, M1),), device=dev())
+    _train.mlp_fwd_train(n0, pts[:, :Nc].contiguous(), vd, acts=acts[:nA])
+    _train.mlp_fwd_train(n1, pts[:, Nc:].contiguous(), vd, acts=acts[nA:])
+    d_raw = T((rs.normal(size=(M0 + M1, 4)) * 10.0 ** rs.uniform(-5, 0, (M0 + M1, 1))).astype(np.float32))
+    gj0, gj1 = _train._new_grads(n0, False), _train._new_grads(n1, False)
+    _train.mlp_backward2(n0, d_raw, acts, gj0, M0, n1, gj1, M1)
+    gs0, gs1 = _train._new_grads(n0, False), _train._new_grads(n1, False)
+    _train.mlp_backward2(n0, d_raw[:M0], acts[:nA], gs0, M0, None, None, 0)
+    _train.mlp_backward2(n1, d_raw[M0:], acts[nA:], gs1, M1, None, None, 0)
+    for a, b in zip(gj0 + gj1, gs0 + gs1):
+        assert l2_err(N(a), N(b)) < 2e-6
+    # accumulate flag: += on top of what is there
+    ga = [t.clone() for t in gs0]
+    _train.mlp_backward2(n0, d_raw[:M0], acts[:nA], ga, M0, None, None, 0, accumulate=True)
+    for a, b in zip(ga, gs0):
+        assert l2_err(N(a), 2.0 * N(b)) < 2e-6

@@ -79,11 +79,11 @@ EXPERIMENTS = {
          '    if (threadIdx.x == 0) {\n'
          '        reinterpret_cast<unsigned long long*>(a.raw)[2 * blockIdx.x] = clock64() - nf_c0;\n'
          '        reinterpret_cast<unsigned long long*>(a.raw)[2 * blockIdx.x + 1] = wall_clock64() - nf_w0;\n    }\n}\n')], []),
-    'dw_clock': ('mlp_bwd.hip', [
-        ('    __shared__ __attribute__((aligned(16))) float smem[kLdsStages * kLdsStageFloats];\n    const int lane = threadIdx.x & 63;\n',
-         '    __shared__ __attribute__((aligned(16))) float smem[kLdsStages * kLdsStageFloats];\n    const unsigned long long nf_w0 = wall_clock64();\n    const int lane = threadIdx.x & 63;\n'),
-        ('            default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;\n        }\n    }\n',
-         '            default: dw_group_lds<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end); break;\n        }\n    }\n'
+    'dw_clock': ('mlp_dw.hip', [
+        ('    __shared__ __attribute__((aligned(16))) float smem[kDwStages * kDwStageFloats];\n    const int lane = threadIdx.x & 63;\n',
+         '    __shared__ __attribute__((aligned(16))) float smem[kDwStages * kDwStageFloats];\n    const unsigned long long nf_w0 = wall_clock64();\n    const int lane = threadIdx.x & 63;\n'),
+        ('            default: dw_group_run<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end, out); break;\n        }\n    }\n',
+         '            default: dw_group_run<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end, out); break;\n        }\n    }\n'
          '    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;\n')], []),
     # K11 segmented reduce pricing: no wave scan (wrong sums) / no gathers (index stream only)
     'seg_noscan': ('gauss_csr.hip', [('            seg_scan_step<0x111>(key[u], v);\n            seg_scan_step<0x112>(key[u], v);\n            seg_scan_step<0x114>(key[u], v);\n            seg_scan_step<0x118>(key[u], v);\n            seg_scan_step<0x142, 0xA>(key[u], v);\n            seg_scan_step<0x143, 0xC>(key[u], v);\n', '')], []),
