@@ -133,6 +133,70 @@ def cpu_baseline(seconds_budget=20.0):
                       % (n, N_CPU, os.cpu_count() or 0, dt)}
 
 
+def cpu_baseline_fwd_bwd(seconds_budget=15.0):
+    """The training step (RN:776-791: render with perturb = 1, the two MSE terms, loss.backward()) as a PyTorch-CPU fp32
+    port (oracle/torch_port.py, pinned to the reference's own gradients by fixture g7) on a bounded ray sample of the
+    1024-ray step, D=8 W=256, 64+128 samples, torch.set_num_threads(cores)."""
+    from oracle import torch_port as TP
+    torch.set_num_threads(N_CPU)
+    sc, sf = synth.nerf_state_dict(seed=31), synth.nerf_state_dict(seed=32)
+    rs = np.random.RandomState(0)
+
+    def run(n, seed):
+        rays = synth.ray_batch(n, seed=seed)
+        target = rs.uniform(size=(n, 3)).astype(np.float32)
+        t_rand, u = rs.uniform(size=(n, N_SAMPLES)).astype(np.float32), rs.uniform(size=(n, N_IMPORTANCE)).astype(np.float32)
+        t = time.time()
+        TP.train_step(rays, sc, sf, target, t_rand, u, N_SAMPLES, N_IMPORTANCE, NET_D)
+        return time.time() - t
+    run(64, 1)                                              # warm-up (thread pools, allocator)
+    per_ray = run(128, 2) / 128
+    n = int(max(128, min(2048, seconds_budget / per_ray)) // 128 * 128)
+    dt = 0.0
+    for s_ in range(0, n, 1024):                            # whole 1024-ray steps (the reference's batch), then the rest
+        dt += run(min(1024, n - s_), 3 + s_)
+    return {'value': n / dt, 'unit': 'rays/s (fwd+bwd)', 'cores': N_CPU, 'kind': 'port',
+            'sample': '%d rays in steps of <= 1024 (64+128 samples, D=8 W=256, perturb=1, coarse+fine MSE, loss.backward(); no '
+                      'optimizer), PyTorch-CPU fp32 port oracle/torch_port.py, torch.set_num_threads(%d), %.1f s' % (n, N_CPU, dt)}
+
+
+def cpu_baseline_attack(seconds_budget=20.0):
+    """The numpy oracle's gauss path of ONE NeRFail-S iteration (oracle/gauss.py: gauss_forward + gauss_backward for each view
+    of the batch, then igsm_step on the [3,800,800,4] perturbation) at full size, on a bounded number of the 8 views."""
+    from oracle import gauss as OG
+    rs = np.random.RandomState(0)
+    P = 3
+    Ns = P * H * W
+    s = np.zeros((P, H, W, 4), np.float32)
+    s[..., 3] = synth.disc_alpha_image(P, H, W, seed=200)[..., 3]
+    G = rs.normal(size=(1, H, W, 4)).astype(np.float32)
+
+    def one_view(seed):
+        # (index / weight maps with the statistics of a K8+K9-built map are not needed for a CPU time: random neighbours)
+        idx = rs.randint(0, Ns, (1, H, W, 8)).astype(np.float32)
+        w = rs.uniform(size=(1, H, W, 8)).astype(np.float32)
+        w /= w.sum(-1, keepdims=True)
+        wi = np.stack([w, idx], 1)
+        ori = synth.disc_alpha_image(1, H, W, seed=seed)
+        t = time.time()
+        OG.gauss_forward(s, wi, ori, None)
+        g = OG.gauss_backward(s, wi, ori, np.zeros_like(G), G, None)
+        return time.time() - t, g
+    t1, g = one_view(1)
+    n_views = int(max(1, min(8, (seconds_budget - t1) / t1)))
+    t_views = t1
+    for v in range(1, n_views):
+        t_views += one_view(1 + v)[0]
+    t = time.time()
+    OG.igsm_step(s, g, s, 2.0, 32.0, False)
+    t_step = time.time() - t
+    per_iter = t_views / n_views * 8 + t_step
+    return {'value': 1.0 / per_iter, 'unit': 'iterations/s (gauss path, batch of 8 views)', 'cores': 1, 'kind': 'port',
+            'sample': '%d of the 8 views of one iteration at 800x800, P=3 (oracle/gauss.py gauss_forward + gauss_backward per view: '
+                      '%.2f s per view, single-threaded numpy gathers / np.add.at) + igsm_step %.2f s; extrapolated to 8 views'
+                      % (n_views, t_views / n_views, t_step)}
+
+
 def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     """NeRF training step (RN:776-801) at the shipped config (configs/lego.txt: N_rand=1024, 64+128 samples,
     D=8 W=256, perturb=1, white_bkgd): render -> mse(rgb)+mse(rgb0) -> backward -> Adam. rays/s (fwd+bwd)."""
@@ -150,11 +214,14 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     c2w = synth.pose_spherical(-180., -30., 4.)[:3, :4]
     all_rays = ray_gen(H, W, K, c2w, 2., 6.)
     gen = torch.Generator(device=dev).manual_seed(0)
+    host_rng = np.random.default_rng(0)
 
     def step():
-        # RN:768 draws the batch with np.random.choice(H*W, N_rand, replace=False): a 640 000-element host permutation
-        # (6-15 ms, longer than the whole GPU step). Same draw on the device instead.
-        sel = torch.randperm(H * W, device=dev, generator=gen)[:n_rand]
+        # RN:768 draws the batch with the LEGACY np.random.choice(H*W, N_rand, replace=False): a 640 000-element host
+        # permutation (6-15 ms, longer than the whole GPU step). Same distribution from numpy's Generator.choice (Floyd's
+        # algorithm: 27 us on the host, which runs ahead of the GPU anyway); the 4 KB of indices go up asynchronously.
+        # (Round 2 drew them with torch.randperm on the device: a 640 000-key sort, ~0.2 ms of GPU time per step.)
+        sel = torch.from_numpy(host_rng.choice(H * W, n_rand, replace=False)).pin_memory().to(dev, non_blocking=True)
         rays = all_rays[sel].contiguous()
         target = torch.rand((n_rand, 3), device=dev, generator=gen)
         t_rand = torch.rand((n_rand, N_SAMPLES), device=dev, generator=gen)
@@ -207,8 +274,8 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
            'final_loss': float(loss.detach()), 'fp32_equivalent_tflops_whole_step': flop / dt / 1e12,
            'statistic': 'median of the %d timed steps' % steps, 'ms_per_step_mean_whole_loop': mean_dt * 1e3, 'warmup': warmup_info,
            'note': 'kernel metric: the step omits the reference loop\'s per-iteration HOST work - get_rays on the full image '
-                   '(RN:752) and np.random.choice(H*W, N_rand) (RN:768, a 6-15 ms host permutation); rays are gathered from a '
-                   'precomputed all_rays with torch.randperm on the device',
+                   '(RN:752); the batch is drawn on the host like RN:768 but with numpy Generator.choice (27 us) instead of the '
+                   'legacy np.random.choice (a 6-15 ms permutation); rays are gathered from a precomputed all_rays',
            'ms_per_step_each': [round(v, 3) for v in per_step]}
     if precision == 'f32':      # the three GEMM families run on the exact-f32 MFMA: that pipe bounds the step
         out['roofline'] = {'bound': 'mfma', 'achieved': flop / dt / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -792,6 +859,12 @@ def main():
         line['cpu_baseline'] = None
         if not args.no_cpu_baseline and world == 1:
             section('cpu_baseline', cpu_baseline)
+            # the same for the other two numbers BASELINE.json's metric string names
+            section('cpu_baseline_fwd_bwd', cpu_baseline_fwd_bwd)
+            section('cpu_baseline_attack', cpu_baseline_attack)
+            for m_, key in zip(metrics[1:3], ('cpu_baseline_fwd_bwd', 'cpu_baseline_attack')):
+                if key in line and m_['metric'].startswith(('rays/sec (fwd+bwd)', 'attack iters/sec (gauss path')):
+                    m_['cpu_baseline'] = line[key]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -356,6 +356,10 @@ typedef struct nerfail_adam_tensor {
 int nerfail_adam_step(const nerfail_adam_tensor* tensors, int n_tensors, double beta1, double beta2, double eps,
                       void* stream);
 
+/* img2mse of the training loss (RH:9, RN:781-789): loss[0] = mean((x - y)^2) over n values by a fixed-order tree, and - when
+ * dx is not NULL - dx[i] = 2 (x[i] - y[i]) / n, the gradient of that mean (one launch instead of ~9 torch kernels). */
+int nerfail_mse(const float* x, const float* y, int64_t n, float* loss, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,7 @@ SIGNATURES = {
     'nerfail_deepfool_apply': (c_i, [c_p, c_i, c_i64, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_igsm_step': (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p]),
     'nerfail_adam_step': (c_i, [c_p, c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_p]),
+    'nerfail_mse': (c_i, [c_p, c_p, c_i64, c_p, c_p, c_p]),
 }
 
 

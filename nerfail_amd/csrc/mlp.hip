@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
 // NERFAIL_FWD_KERNEL=reg|lds force one of them (A/B timing, parity test of one against the other).
 static int g_fwd_select = [] { const char* e = getenv("NERFAIL_FWD_KERNEL"); return e ? (e[0] == 'r' ? 1 : (e[0] == 'l' ? 2 : 0)) : 0; }();
 static bool use_lds_kernel(const MlpArgs& a) {
-    if (g_fwd_select == 1 || a.acts != nullptr) return false;
+    if (g_fwd_select == 1) return false;
     if (g_fwd_select == 2) return true;
     return !(a.lay.D & 1) && a.lay.D <= 8;
 }

@@ -129,8 +129,10 @@ struct WRing {
     // `cur` with s_waitcnt lgkmcnt(0), which is free only while the reads of the NEXT step have not been issued yet.
     // pre() runs before the MFMAs (work the step itself needs), mid() behind the first tile's MFMAs and the prefetch
     // (work for LATER steps: the next quad's B operands).
-    template <int HSP, bool SYNC, class PRE, class MID, class MF>
-    __device__ __forceinline__ void step(PRE&& pre, MID&& mid, MF&& mf) {
+    // post(k) runs behind MFMA k of the step (training: ONE activation store per MFMA - four stores issued back to back
+    // drained the matrix pipe: a global store takes about as long to issue as an MFMA runs).
+    template <int HSP, bool SYNC, class PRE, class MID, class MF, class POST>
+    __device__ __forceinline__ void step(PRE&& pre, MID&& mid, MF&& mf, POST&& post) {
         f32x4 cur[HSP];
 #pragma unroll
         for (int t = 0; t < HSP; ++t) cur[t] = fr[t];
@@ -149,6 +151,7 @@ struct WRing {
                     dma(k);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                post(k);
                 ++k;
             }
             if (t == 0) {
@@ -187,8 +190,13 @@ struct WRing {
 //                matrix pipe (~10 cycles each even when nothing waits for it, tools/clockprobe/mfma_patterns.hip); read
 //                right in front of the MFMA that needs it, it cost 24 (70.0 instead of 66.5 cycles per MFMA).
 //   hook(q):     side work at the start of quad q (bias tiles of the next layer into dead registers).
-template <int NT, int OT, int NQ, int PAD, int NIN, class Hook, class BPrep>
-__device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook hook, BPrep bprep) {
+//   tstore(q, e, b): training only - operand e of quad q leaves for HBM (saved activations) and enters the ReLU bit mask.
+//                Issued behind MFMAs 4..7 of the quad's FIRST step, one per MFMA: b[] is live for the whole quad anyway,
+//                and a store issued there is old enough at the next group boundary (the boundary's counted vmcnt leaves
+//                only the 8 youngest vector-memory operations in flight; stores count like LDS-DMAs, in order).
+struct NoStore { __device__ __forceinline__ void operator()(int, int, const float (&)[4]) const {} };
+template <int NT, int OT, int NQ, int PAD, int NIN, class Hook, class BPrep, class TStore = NoStore>
+__device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook hook, BPrep bprep, TStore tstore = TStore()) {
     using C = LdsCfg<NT>;
     constexpr int HSP = OT >= 4 ? 4 : OT, SPQ = OT / HSP;
     static_assert((NQ * OT + PAD) % C::GP == 0, "a part is a whole number of ring groups");
@@ -204,8 +212,15 @@ __device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook
             };
             auto pr = [&]() { if (sp == 0) hook(q); };
             auto mid = [&]() { if (sp == SPQ - 1 && q + 1 < NQ) bprep(q + 1, bq[q + 1]); };
-            if (done % C::GP == 0) st.template step<HSP, true>(pr, mid, mf);
-            else st.template step<HSP, false>(pr, mid, mf);
+            constexpr int K0 = 4 * HSP >= 8 ? 4 : 0;                 // behind MFMAs 4..7 (a one-tile step has only 0..3)
+            auto post = [&](int k) {
+                if (sp == 0 && k >= K0 && k < K0 + 4) {
+                    tstore(q, k - K0, bq[q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (done % C::GP == 0) st.template step<HSP, true>(pr, mid, mf, post);
+            else st.template step<HSP, false>(pr, mid, mf, post);
         }
     }
 #pragma unroll
@@ -221,6 +236,25 @@ __device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook
 __device__ __forceinline__ float relu_bits(float x) {
     const int i = __float_as_int(x);
     return __int_as_float(i > 0 ? i : 0);
+}
+
+// ---- training stores. Written as inline asm in the "SGPR base + 32-bit lane offset + immediate" form: ONE VGPR (the lane's
+// offset inside a slot) serves every saved value of the kernel. Left to hipcc, each destination became a 64-bit per-lane
+// pointer pair that was hoisted and spilled, and a scratch reload drains the LDS-DMA queue (vmcnt retires in order).
+// (The register's byte offset is added in a VGPR behind an opaque copy - one v_add per store, never hoisted; an "n"
+// immediate would need the register index as a front-end constant, and a 16-way switch per store kept hipcc from unrolling.)
+__device__ __forceinline__ void st_acc_reg(const float* sbase, unsigned voff, int r, float v) {
+    unsigned o = voff;
+    asm volatile("" : "+v"(o));
+    o += (unsigned)(acc_reg_off(r) * 4);
+    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(o), "v"(v), "s"(sbase) : "memory");
+}
+// the 16 ReLU bits of one accumulator tile: entry's [64 lanes][4 dwords] image, tile t = 16-bit field t of the lane
+__device__ __forceinline__ void st_mask16(const float* sentry, unsigned vlane16, int t, unsigned bits) {
+    unsigned o = vlane16;
+    asm volatile("" : "+v"(o));
+    o += (unsigned)(2 * t);
+    asm volatile("global_store_short %0, %1, %2" ::"v"(o), "v"(bits), "s"(sentry) : "memory");
 }
 
 // dot product of a thin head's weights (LDS, accumulator order [OT][2][16]) with relu(x): VALU + one cross-half shuffle.
@@ -248,7 +282,9 @@ __device__ __forceinline__ float lds_head(const f32x16 (&x)[NIN], const float* w
 }
 
 // SKIP: where the skip connection's extra part is compiled in: 0 nowhere, 1 first / 2 second layer of a pair.
-template <int NT, int SKIP>
+// TRAIN: additionally saves what the backward needs (mlp_layout.h: encodings, every layer's post-ReLU tile, the feature
+// tile, ReLU bit masks) - same values, same slots as the register-streamed nerf_mlp_fwd_kernel<NT, true>.
+template <int NT, int SKIP, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
     using C = LdsCfg<NT>;
     constexpr int OTV = NT / 2;
@@ -320,6 +356,20 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
 #pragma unroll
         for (int k = 0; k < kDirQuads; ++k)
             *reinterpret_cast<f32x4*>(park + (kEmbQuads + k) * 256) = (f32x4){demb[4 * k], demb[4 * k + 1], demb[4 * k + 2], demb[4 * k + 3]};
+        // training: this tile's slots. A wave without a tile of its own recomputes the last tile and writes the SAME bytes
+        // again (no branch in the pinned schedule).
+        float* __restrict__ A = nullptr;                                                  // wave-uniform
+        unsigned voff = 0, vlane16 = 0;                                                   // lane offsets (bytes) in a slot / a mask entry
+        if (TRAIN) {
+            A = a.acts + (size_t)tile * (train_a_slots(L.D, NT) * 1024);
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));                                                  // recomputed per tile (see jj above)
+            voff = (unsigned)acc_lane_off(l2) * 4u;
+            vlane16 = (unsigned)l2 * 16u;
+            store_enc<10, 4 * kEmbQuads>(A, emb, lane);                                   // E0 E1: 63 channels
+            store_enc<4, 4 * kDirQuads>(A + 2 * 1024, demb, lane);                        // V: 27 channels
+        }
+        const float* const Amask = TRAIN ? A + train_mask_slot0(L.D, NT) * 1024 : nullptr;
         auto b_park = [&](int q, float (&b)[4]) {                                         // quad q of the parked operands
             const f32x4 v = lds_read4(park + q * 256);
 #pragma unroll
@@ -340,12 +390,27 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
             if (may_be_last && l == L.D) alpha = lds_head<NT>(in, c_alpha, h) + c_alpha[NT * 32];   // alpha_linear on relu(h) (RH:110)
             if (may_skip && l == L.skip + 1)                                              // h = cat([input_pts, h]) (RH:106-107)
                 lds_part<NT, NT, kEmbQuads, 0>(st, out, [](int) {}, b_park);
-            lds_part<NT, NT, 4 * NT, 0>(st, out,
-                [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); },
-                [&](int q, float (&b)[4]) {                                               // lazy ReLU of quad q's 4 accumulator registers
+            unsigned mk16 = 0u;                                                           // ReLU bits of the tile being consumed
+            const float* const Hl = TRAIN ? A + (3 + (l - 1) * NT) * 1024 : nullptr;      // H_l = relu(in): layer l's input
+            const float* const Ml = TRAIN ? Amask + (l - 1) * 256 : nullptr;              // its bit-mask entry
+            auto bp = [&](int q, float (&b)[4]) {                                         // lazy ReLU of quad q's 4 accumulator registers
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);
+                for (int e = 0; e < 4; ++e) b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);
+            };
+            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); };
+            if constexpr (TRAIN) {
+                lds_part<NT, NT, 4 * NT, 0>(st, out, hk, bp, [&](int q, int e, const float (&b)[4]) {
+                    const int r = 4 * (q & 3) + e;
+                    st_acc_reg(Hl + (q >> 2) * 1024, voff, r, b[e]);
+                    mk16 |= relu_bit(b[e]) << r;
+                    if (r == 15) {
+                        st_mask16(Ml, vlane16, q >> 2, mk16);
+                        mk16 = 0u;
+                    }
                 });
+            } else {
+                lds_part<NT, NT, 4 * NT, 0>(st, out, hk, bp);
+            }
             bias_tile(in, l + 1, NT - 1);
         };
 #pragma unroll 1
@@ -355,14 +420,41 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
         }
         // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q's first tiles (RH:112-116; its ReLU is applied by
         // the rgb head); P, its input, receives the bias of the NEXT tile's layer 0 as it dies
-        lds_part<NT, OTV, 4 * NT, 0>(st, Q,
-            [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(P, 0, (q >> 2) - 1); },
-            [&](int q, float (&b)[4]) {
+        {
+            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(P, 0, (q >> 2) - 1); };
+            auto bp = [&](int q, float (&b)[4]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b[e] = P[q >> 2][4 * (q & 3) + e];
-            });
+            };
+            if constexpr (TRAIN) {
+                const float* const Fl = A + (3 + L.D * NT) * 1024;                        // F = feature_linear's output (no activation)
+                lds_part<NT, OTV, 4 * NT, 0>(st, Q, hk, bp, [&](int q, int e, const float (&b)[4]) {
+                    st_acc_reg(Fl + (q >> 2) * 1024, voff, 4 * (q & 3) + e, b[e]);
+                });
+            } else {
+                lds_part<NT, OTV, 4 * NT, 0>(st, Q, hk, bp);
+            }
+        }
         bias_tile(P, 0, NT - 1);
         lds_part<NT, OTV, kDirQuads, C::kStreamPad>(st, Q, [](int) {}, [&](int q, float (&b)[4]) { b_park(kEmbQuads + q, b); });
+        if constexpr (TRAIN) {                                                            // HV = relu(views output) + its bit mask
+            const float* const Vl = A + (3 + (L.D + 1) * NT) * 1024;
+#pragma unroll
+            for (int t = 0; t < OTV; ++t) {
+                unsigned mv = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = Q[t][r];
+                    asm("" : "+v"(v));
+                    v = relu_bits(v);
+                    st_acc_reg(Vl + t * 1024, voff, r, v);
+                    mv |= relu_bit(v) << r;
+                }
+                st_mask16(Amask + L.D * 256, vlane16, t, mv);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (OTV & 1) st_mask16(Amask + L.D * 256, vlane16, OTV, 0u);                 // the dword's unused half, as store_mask writes it
+        }
         float rgb[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)                                                       // rgb_linear: W/2 -> 3 (RH:118)
@@ -386,9 +478,17 @@ static int launch_lds(const MlpArgs& a, unsigned blocks, hipStream_t s) {
     }
     if ((a.lay.D & 1) || a.lay.D > C::kMaxDepth) { set_error("nerf_mlp_fwd_lds_kernel: depth not covered"); return NERFAIL_EINVAL; }
     const int skip_layer = a.lay.skip >= 0 ? a.lay.skip + 1 : -1;                         // layer that takes the extra part
-    if (skip_layer < 0) nerf_mlp_fwd_lds_kernel<NT, 0><<<dim3(blocks), dim3(256), 0, s>>>(a);
-    else if (skip_layer & 1) nerf_mlp_fwd_lds_kernel<NT, 1><<<dim3(blocks), dim3(256), 0, s>>>(a);
-    else nerf_mlp_fwd_lds_kernel<NT, 2><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    const bool train = a.acts != nullptr;
+    if (skip_layer < 0) {
+        if (train) nerf_mlp_fwd_lds_kernel<NT, 0, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
+        else nerf_mlp_fwd_lds_kernel<NT, 0, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    } else if (skip_layer & 1) {
+        if (train) nerf_mlp_fwd_lds_kernel<NT, 1, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
+        else nerf_mlp_fwd_lds_kernel<NT, 1, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    } else {
+        if (train) nerf_mlp_fwd_lds_kernel<NT, 2, true><<<dim3(blocks), dim3(256), 0, s>>>(a);
+        else nerf_mlp_fwd_lds_kernel<NT, 2, false><<<dim3(blocks), dim3(256), 0, s>>>(a);
+    }
     NF_LAUNCHED("nerf_mlp_fwd_lds_kernel");
     return NERFAIL_OK;
 }

@@ -346,3 +346,36 @@ def test_lds_streaming_kernel_equals_register_streamed_kernel():
             assert float(out[1].abs().max()) > 0
     finally:
         lib.nerfail_mlp_fwd_select(0)
+
+
+def test_lds_training_forward_saves_the_same_bits_as_the_register_kernel():
+    """Round 3: the training forward runs on the LDS-ring kernel too (mlp_lds.hip, TRAIN). Everything it saves for the
+    backward - encodings, every layer's post-ReLU tile, the feature tile, the views tile, the ReLU bit masks - and `raw`
+    must equal the register-streamed nerf_mlp_fwd_kernel<NT, true> BITWISE (same FMA chains, same slots), incl. a
+    ragged last tile and waves without a tile of their own."""
+    from nerfail_amd import _lib, _train
+    lib = _lib.load()
+    rs = np.random.RandomState(4)
+    try:
+        for (D, W, seed, R, Ns) in ((8, 256, 12, 1500, 64), (8, 256, 13, 37, 5), (4, 64, 14, 301, 192)):
+            _, net = hip_nerf(D, W, seed, requires_grad=True)
+            pts = T(rs.uniform(-3, 3, size=(R, Ns, 3)).astype(np.float32))
+            vd = rs.normal(size=(R, 3)).astype(np.float32)
+            vd = T(vd / np.linalg.norm(vd, axis=1, keepdims=True))
+            out = {}
+            for which in (1, 2):
+                lib.nerfail_mlp_fwd_select(which)
+                n = _train.acts_floats(net, R * Ns)
+                acts = torch.full((n,), float('nan'), device=dev())
+                raw, acts = _train.mlp_fwd_train(net, pts, vd, acts=acts)
+                out[which] = (raw.clone(), acts.clone())
+            assert torch.equal(out[1][0].view(torch.int32), out[2][0].view(torch.int32)), (D, W, 'raw')
+            a1, a2 = out[1][1].view(torch.int32), out[2][1].view(torch.int32)
+            if (R * Ns) % 32 == 0:
+                assert torch.equal(a1, a2), (D, W, 'acts', int((a1 != a2).sum()))
+            else:   # the padding samples of the ragged last tile are whatever the clamped sample gives: compare whole tiles only
+                per_tile = n // ((R * Ns + 31) // 32)
+                full = (R * Ns) // 32 * per_tile
+                assert torch.equal(a1[:full], a2[:full]), (D, W, 'acts of the full tiles')
+    finally:
+        lib.nerfail_mlp_fwd_select(0)

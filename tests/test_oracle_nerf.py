@@ -179,3 +179,23 @@ def test_mlp_backward_on_identical_inputs(golden):
         worst = max(worst, e / (2 * float(g['ref_err_' + k]) + 2e-6))
         assert e <= 2 * float(g['ref_err_' + k]) + 2e-6, (k, e, float(g['ref_err_' + k]))
     print('oracle mlp_backward vs reference autograd: worst error / bound = %.2f' % worst)
+
+
+def test_torch_port_matches_reference_training_step(golden):
+    """oracle/torch_port.py (the PyTorch-CPU port timed as bench.py's cpu_baseline_fwd_bwd) against the reference's own
+    loss.backward() on identical rays and draws (fixture g7, D=4 W=64: every gradient stored; D=8 W=256: norms + heads)."""
+    from oracle import torch_port as TP
+    import synth
+    g = golden('g7_train_grads')
+    for tag, D, W in (('small', 4, 64), ('full', 8, 256)):
+        sc, sf = synth.nerf_state_dict(D=D, W=W, seed=31), synth.nerf_state_dict(D=D, W=W, seed=32)
+        loss, gc, gf = TP.train_step(g[tag + '_rays'], sc, sf, g[tag + '_target'], g[tag + '_t_rand'], g[tag + '_u'], D=D)
+        assert abs(loss - float(g[tag + '_loss'])) < 1e-6 * abs(float(g[tag + '_loss']))
+        for nm, grads in (('coarse', gc), ('fine', gf)):
+            for k, got in grads.items():
+                if tag == 'small':
+                    ref = g['small_%s_grad_%s' % (nm, k)]
+                    assert np.linalg.norm(got - ref) <= 1e-4 * max(np.linalg.norm(ref), 1e-12), (nm, k)
+                else:
+                    refn = float(g['full_%s_gradnorm_%s' % (nm, k)])
+                    assert abs(np.linalg.norm(got.astype(np.float64)) - refn) < 1e-4 * refn, (nm, k)

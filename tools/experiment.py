@@ -47,7 +47,7 @@ EXPERIMENTS = {
          '            o_[0] = (unsigned)(c1_ - c0_); o_[1] = (unsigned)(c2_ - c1_); o_[2] = (unsigned)(c3_ - c2_); o_[3] = (unsigned)(c4_ - c3_);\n'
          '            o_[4] = __float_as_uint(rgb[0] + rgb[1] + rgb[2] + alpha); o_[5] = (unsigned)wall_clock64();\n'
          '        }\n')], []),
-    'lds_nobias': ('mlp_lds.hip', [('                [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); },\n', '                [&](int q) {},\n'),
+    'lds_nobias': ('mlp_lds.hip', [('            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); };\n', '            auto hk = [&](int q) {};\n'),
                                    ('            bias_tile(in, l + 1, NT - 1);\n', '')], []),
     'lds_norelu': ('mlp_lds.hip', [('b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);', 'b[e] = in[q >> 2][4 * (q & 3) + e];')], []),
     'lds_noread': ('mlp_lds.hip', [('        for (int t = 0; t < C::HS; ++t) fr[t] = lds_read4(rl + (rd + t) * kPiece);\n    }\n    __device__ __forceinline__ void start()',
@@ -85,6 +85,13 @@ EXPERIMENTS = {
         ('            default: dw_group_run<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end, out); break;\n        }\n    }\n',
          '            default: dw_group_run<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end, out); break;\n        }\n    }\n'
          '    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;\n')], []),
+    # pricing of the weight-gradient step loop (mlp_dw.hip): no LDS-DMA / no per-step barrier / no LDS operand reads / no row sums
+    'dw_nodma': ('mlp_dw.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + voff[i]),\n                                         (lds_void_t*)(smem + rs * kDwStageFloats + (wave + 4 * i) * 256), 16, 0, 0);\n',
+                                 '        asm volatile("" :: "v"(base + voff[i]), "s"(rs));\n')], []),
+    'dw_nobarrier': ('mlp_dw.hip', [('                dw_wait_vmcnt<(NS - 3) * G>();                          // this wave\'s pieces of stage s+1 have landed\n                __builtin_amdgcn_s_barrier();',
+                                     '                dw_wait_vmcnt<(NS - 3) * G>();                          // this wave\'s pieces of stage s+1 have landed\n')], []),
+    'dw_nofetch': ('mlp_dw.hip', [('        R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n', '        if (off == -12345) R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n')], []),
+    'dw_norowsum': ('mlp_dw.hip', [('                rowsum[m] = rowsum[m] + (R[P][m][0] + R[P][m][1]);\n', '')], []),
     # K11 segmented reduce pricing: no wave scan (wrong sums) / no gathers (index stream only)
     'seg_noscan': ('gauss_csr.hip', [('            seg_scan_step<0x111>(key[u], v);\n            seg_scan_step<0x112>(key[u], v);\n            seg_scan_step<0x114>(key[u], v);\n            seg_scan_step<0x118>(key[u], v);\n            seg_scan_step<0x142, 0xA>(key[u], v);\n            seg_scan_step<0x143, 0xC>(key[u], v);\n', '')], []),
     'seg_nogather': ('gauss_csr.hip', [('            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> (PACKED ? 1 : 3)) * C + c];', '            for (int c = 0; c < C; ++c) g[u][c] = make_float4((float)id[u], 1.f, 2.f, 3.f);')], []),
