@@ -22,6 +22,7 @@
 //     activation arrays swap roles from layer to layer: no copy, no ReLU pass at a layer boundary.
 //   * biases and the two thin heads live in a constant LDS area loaded once per workgroup.
 // Bound: f32 MFMA (157.3 TFLOP/s dense); 1 186 816 FLOP per sample (D8 W256). LDS: 12*NT KB ring + 14 KB constants + 48 KB parked operands.
+#include <type_traits>
 #include "mlp_layout.h"
 
 namespace nerfail {
@@ -97,8 +98,12 @@ struct WRing {
     // Group boundary: every wave's pieces of the next group have landed (counted wait: the S-2 younger groups stay
     // in flight), every wave's reads of the group just finished have returned -> one barrier makes the first
     // readable for all and the second's slot free for all.
+    // EXTRA: vector-memory operations that are NOT LDS-DMAs (training stores) and are known to have been issued after the
+    // youngest DMA of the group that is allowed to stay in flight: vmcnt counts them all, in issue order.
+    template <int EXTRA = 0>
     __device__ __forceinline__ void boundary() const {
-        lds_wait_vmcnt<(C::S - 2) * C::GPW>();
+        static_assert((C::S - 2) * C::GPW + EXTRA <= 63, "vmcnt is a 6-bit counter");
+        lds_wait_vmcnt<(C::S - 2) * C::GPW + EXTRA>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -131,14 +136,14 @@ struct WRing {
     // (work for LATER steps: the next quad's B operands).
     // post(k) runs behind MFMA k of the step (training: ONE activation store per MFMA - four stores issued back to back
     // drained the matrix pipe: a global store takes about as long to issue as an MFMA runs).
-    template <int HSP, bool SYNC, class PRE, class MID, class MF, class POST>
+    template <int HSP, bool SYNC, int EXTRA = 0, class PRE, class MID, class MF, class POST>
     __device__ __forceinline__ void step(PRE&& pre, MID&& mid, MF&& mf, POST&& post) {
         f32x4 cur[HSP];
 #pragma unroll
         for (int t = 0; t < HSP; ++t) cur[t] = fr[t];
         rd += HSP;
         if (rd >= C::RP) rd = 0;
-        if (SYNC) boundary();
+        if (SYNC) boundary<EXTRA>();
         __builtin_amdgcn_sched_barrier(0);
         pre();
         int k = 0;
@@ -214,12 +219,20 @@ __device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook
             auto mid = [&]() { if (sp == SPQ - 1 && q + 1 < NQ) bprep(q + 1, bq[q + 1]); };
             constexpr int K0 = 4 * HSP >= 8 ? 4 : 0;                 // behind MFMAs 4..7 (a one-tile step has only 0..3)
             auto post = [&](int k) {
-                if (sp == 0 && k >= K0 && k < K0 + 4) {
-                    tstore(q, k - K0, bq[q]);
-                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!std::is_same<TStore, NoStore>::value) {
+                    if (sp == 0 && k >= K0 && k < K0 + 4) {
+                        tstore(q, k - K0, bq[q]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             };
-            if (done % C::GP == 0) st.template step<HSP, true>(pr, mid, mf, post);
+            // Training stores of a part: 4 per quad, all issued AFTER the refill DMAs of the group interval they fall into
+            // (the DMAs stand behind the first MFMAs of the interval's first step, which carries no store), and every
+            // interval that ends inside this part holds exactly 4 * (quads per group) of them. They may therefore stay in
+            // flight across the boundary together with the youngest group - otherwise every boundary would wait for
+            // stores issued ~1.7 us earlier to be acknowledged.
+            constexpr int EXTRA = std::is_same<TStore, NoStore>::value ? 0 : 4 * (C::GP / OT);
+            if (done % C::GP == 0) st.template step<HSP, true, EXTRA>(pr, mid, mf, post);
             else st.template step<HSP, false>(pr, mid, mf, post);
         }
     }
@@ -241,20 +254,15 @@ __device__ __forceinline__ float relu_bits(float x) {
 // ---- training stores. Written as inline asm in the "SGPR base + 32-bit lane offset + immediate" form: ONE VGPR (the lane's
 // offset inside a slot) serves every saved value of the kernel. Left to hipcc, each destination became a 64-bit per-lane
 // pointer pair that was hoisted and spilled, and a scratch reload drains the LDS-DMA queue (vmcnt retires in order).
-// (The register's byte offset is added in a VGPR behind an opaque copy - one v_add per store, never hoisted; an "n"
-// immediate would need the register index as a front-end constant, and a 16-way switch per store kept hipcc from unrolling.)
+// (The register's byte offset rides in the instruction's immediate: an "i" operand, constant once the quad loops are
+// unrolled - "n" would demand a front-end constant, a 16-way switch per store kept hipcc from unrolling, and adding the
+// offset in a VGPR cost a v_mov + v_add + s_nop per store in an MFMA shadow that is 64 cycles long.)
 __device__ __forceinline__ void st_acc_reg(const float* sbase, unsigned voff, int r, float v) {
-    unsigned o = voff;
-    asm volatile("" : "+v"(o));
-    o += (unsigned)(acc_reg_off(r) * 4);
-    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(o), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(v), "s"(sbase), "i"(acc_reg_off(r) * 4) : "memory");
 }
 // the 16 ReLU bits of one accumulator tile: entry's [64 lanes][4 dwords] image, tile t = 16-bit field t of the lane
 __device__ __forceinline__ void st_mask16(const float* sentry, unsigned vlane16, int t, unsigned bits) {
-    unsigned o = vlane16;
-    asm volatile("" : "+v"(o));
-    o += (unsigned)(2 * t);
-    asm volatile("global_store_short %0, %1, %2" ::"v"(o), "v"(bits), "s"(sentry) : "memory");
+    asm volatile("global_store_short %0, %1, %2 offset:%3" ::"v"(vlane16), "v"(bits), "s"(sentry), "i"(2 * t) : "memory");
 }
 
 // dot product of a thin head's weights (LDS, accumulator order [OT][2][16]) with relu(x): VALU + one cross-half shuffle.

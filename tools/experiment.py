@@ -85,6 +85,15 @@ EXPERIMENTS = {
         ('            default: dw_group_run<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end, out); break;\n        }\n    }\n',
          '            default: dw_group_run<BF16, 1, 2, 1, 8>(a, grp, smem, lane, wave, t_begin, t_end, out); break;\n        }\n    }\n'
          '    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;\n')], []),
+    # pricing of the training stores of the LDS-ring forward (mlp_lds.hip, TRAIN): default cache policy instead of nt / no
+    # activation stores at all (backward then reads garbage: timing only) / no ReLU bit masks
+    'lds_train_nont': ('mlp_lds.hip', [('    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n',
+                                       '    asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n')], []),
+    'lds_train_nostore': ('mlp_lds.hip', [('    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n',
+                                          '    asm volatile("" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n')], []),
+    'lds_train_nomask': ('mlp_lds.hip', [('    asm volatile("global_store_short %0, %1, %2" ::"v"(o), "v"(bits), "s"(sentry) : "memory");\n',
+                                         '    asm volatile("" ::"v"(o), "v"(bits), "s"(sentry) : "memory");\n'),
+                                        ('                    mk16 |= relu_bit(b[e]) << r;\n', '')], []),
     # pricing of the weight-gradient step loop (mlp_dw.hip): no LDS-DMA / no per-step barrier / no LDS operand reads / no row sums
     'dw_nodma': ('mlp_dw.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + voff[i]),\n                                         (lds_void_t*)(smem + rs * kDwStageFloats + (wave + 4 * i) * 256), 16, 0, 0);\n',
                                  '        asm volatile("" :: "v"(base + voff[i]), "s"(rs));\n')], []),
