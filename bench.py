@@ -504,7 +504,7 @@ def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
     st = _lib.stream()
     calls = {
         'K10_gauss_fwd': (lambda: lib.nerfail_gauss_fwd(_lib.dev(s), Ns, _lib.dev(wi), _lib.dev(ori), B, P, -1.0, _lib.dev(x), _lib.dev(xr), None, st),
-                          B * 102.4e6, ('gauss_fwd_kernel',)),
+                          B * 102.4e6, ('gauss_fwd_views_kernel',)),
         'K11_gauss_bwd_views': (lambda: lib.nerfail_gauss_bwd_views(_lib.dev(ori), _lib.dev(x), None, _lib.dev(G), table, B, Ns, P, -1.0,
                                                                    _lib.dev(scratch), _lib.dev(gs), st),
                                 B * 81.9e6, ('gauss_pixel_grad_kernel', 'gauss_seg_reduce_views_kernel', 'gauss_seg_combine_views_kernel', 'gauss_rows_sum_kernel')),

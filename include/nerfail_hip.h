@@ -238,6 +238,20 @@ int nerfail_gauss_fwd(const float* spatial, int64_t Ns, const float* weight_and_
                       int64_t B, int64_t P, float epsilon, float* x, float* x_rgba, float* eps_minmax,
                       void* stream);
 
+/* The same over views that are addressed ONE BY ONE (host table of n_views entries; all pointers device memory): the
+ * device-resident maps of the attack loop, kept per view id instead of re-uploaded per iteration (MyDataset.py:199-204
+ * hands out a freshly loaded 41 MB map per view and step). ori_is_u8: ori_img entries are uint8 [P,4] BGRA as cv2.imread
+ * delivers them (MyDataset.py:200), else float32 [P,4]. x may be NULL (GN:83's tensor is not needed by the attack step);
+ * aux_alpha [n_views*P] / aux_mask [n_views*P] (both or neither) receive alpha = x_3 / 255 and the 3-bit mask "channel c
+ * passes its gradient" - all nerfail_gauss_bwd_views_rgb needs. Outputs are indexed [view][pixel] like a batch tensor. */
+typedef struct nerfail_view_fwd {
+    const float* weight_and_index;  /* [2,P,8] float32: weights, then indices (as float) */
+    const void* ori_img;            /* [P,4] uint8 or float32 */
+} nerfail_view_fwd;
+int nerfail_gauss_fwd_views(const float* spatial, int64_t Ns, const nerfail_view_fwd* views, int n_views, int64_t P,
+                            int ori_is_u8, float epsilon, float* x, float* x_rgba, float* aux_alpha, unsigned char* aux_mask,
+                            float* eps_minmax, void* stream);
+
 /* Backward of the above (autograd of GN:63-119): grad_spatial[Ns,4] += d/ds( sum(x*grad_x) +
  * sum(x_rgba*grad_x_rgba) ). grad_x / grad_x_rgba may be NULL (treated as zero). x is the forward's
  * saved output. grad_spatial is ACCUMULATED into (zero it first for a fresh gradient) with float atomics. */
@@ -301,6 +315,13 @@ size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_index* views, i
 int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
                             const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
                             float* scratch, float* grad_spatial, void* stream);
+/* The rgb-gradient-only form for the NeRFail-S step (AS:357-392 never reads the alpha channel's gradient): upstream
+ * gradient w.r.t. x_rgba only, per-pixel chain from nerfail_gauss_fwd_views' aux outputs (5 bytes per pixel instead of
+ * x and ori), result as grad_rgb [Ns,3] - the buffer the perturbation-gradient all-reduce moves. Same sums, same order
+ * as nerfail_gauss_bwd_views: the three channels are bitwise equal to its rgb channels. Same scratch size. */
+int nerfail_gauss_bwd_views_rgb(const float* aux_alpha, const unsigned char* aux_mask, const float* grad_x_rgba,
+                                const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float* scratch,
+                                float* grad_rgb, void* stream);
 /* ONE view, n_rhs (1..8) upstream gradients at once - the class-logit gradients of one DeepFool iteration (deepfool.py:
  * 66-96 takes them one autograd.grad call at a time). grad_x_rgba: [n_rhs][P,4]; grad_spatial: [n_rhs][Ns,4],
  * overwritten. Sums run in the same order as nerfail_gauss_bwd_views, so each right-hand side gets bitwise the result of
@@ -336,6 +357,9 @@ int nerfail_deepfool_apply(const float* grads, int n_rhs, int64_t n, const int32
  * init +- epsilon; alpha channel copied. spatial/grad/spatial_init/out are [n,4]; out may alias spatial. */
 int nerfail_igsm_step(const float* spatial, const float* grad, const float* spatial_init, int64_t n,
                       float a, float epsilon, int targeted, float* out, void* stream);
+/* The same with the gradient as [n,3] (rgb only, nerfail_gauss_bwd_views_rgb's output). */
+int nerfail_igsm_step_rgb(const float* spatial, const float* grad_rgb, const float* spatial_init, int64_t n, float a,
+                          float epsilon, int targeted, float* out, void* stream);
 
 /* K13 - one optimizer step of the NeRF training loop for ALL parameter tensors in one launch. Replaces
  * optimizer.step() of torch.optim.Adam(params, lr, betas=(0.9, 0.999)) (run_nerf.py:207, :792): no weight decay, no

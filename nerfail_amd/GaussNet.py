@@ -6,6 +6,7 @@ sum, alpha, epsilon clip, composite onto the image) is one HIP kernel with a han
 classifier) stays stock PyTorch, as SURVEY.md section 8(a16) scopes it.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -68,14 +69,20 @@ class ViewIndex:
     ARRAYS = ('packed', 'w_sorted', 'chunk_ord', 'pos')
 
     def __init__(self, wi_view=None, Ns=None, state=None):
+        self.verified = False          # set once the index has been checked against (or built from) a map seen in this process
         if state is not None:
             self.Ns, self.P = int(state['Ns']), int(state['P'])
             self.n_entries, self.n_rows = int(state['n_entries']), int(state['n_rows'])
+            self.fp = tuple(state['fp']) if state.get('fp') is not None else None
+            self.src = state.get('src')                  # (mtime_ns, size) of the map file the index was built from
             dev = _cuda()
             for k in self.ARRAYS:
                 setattr(self, k, state[k].to(dev).contiguous())
             return
         lib = _lib.load()
+        self.fp = fingerprints(wi_view.unsqueeze(0) if wi_view.dim() == 4 else wi_view)[0]      # content key of the map
+        self.src = None
+        self.verified = True
         full = GaussCSR(wi_view.unsqueeze(0) if wi_view.dim() == 4 else wi_view, Ns)     # sorted entries (B = 1), temporary
         dev = full.row_ptr.device
         cap = full.contrib.numel()
@@ -108,7 +115,7 @@ class ViewIndex:
 
     def state_dict(self):
         d = {k: getattr(self, k).cpu() for k in self.ARRAYS}
-        d.update(Ns=self.Ns, P=self.P, n_entries=self.n_entries, n_rows=self.n_rows)
+        d.update(Ns=self.Ns, P=self.P, n_entries=self.n_entries, n_rows=self.n_rows, fp=self.fp, src=self.src)
         return d
 
     def save(self, path):
@@ -123,6 +130,9 @@ def view_table(indices):
     """Host table of nerfail_view_index structs for nerfail_gauss_bwd_views, and the floats of scratch that call needs."""
     table = (_lib.ViewIndexStruct * len(indices))()
     for b, vi in enumerate(indices):
+        if vi.P != indices[0].P or vi.Ns != indices[0].Ns:
+            raise ValueError('view indices of different image / table sizes in one batch: P %d vs %d, Ns %d vs %d'
+                             % (vi.P, indices[0].P, vi.Ns, indices[0].Ns))
         vi.fill(table[b])
     return table, _lib.load().nerfail_gauss_bwd_views_scratch_floats(table, len(indices), indices[0].P, 1)
 
@@ -140,141 +150,343 @@ def fingerprints(wi):
     return [('fp',) + tuple(int(v) for v in row) + tuple(wi.shape[1:]) for row in out.cpu().tolist()]
 
 
-def view_indices(wi, Ns, view_ids=None):
-    """The ViewIndex of every view of the batch tensor `wi`, built on first sight and cached per VIEW.
+def _view_key(v, Ns):
+    return ('id', v if isinstance(v, (str, bytes, tuple)) else int(v), int(Ns))
 
-    Key of a view: `view_ids[b]` when the caller names its views (dataset indices: free), else a content fingerprint of
-    the view's map, so that the anonymous, freshly collated tensors a DataLoader yields (new address every iteration,
-    MyDataset.py:199-204) still find their index. A resident tensor that is passed again (same address and version) skips
-    the fingerprint."""
+
+def view_indices(wi, Ns, view_ids=None):
+    """The ViewIndex of every view of the batch `wi` (a tensor [B,2,H,W,8] or a list of per-view tensors [2,H,W,8]), built
+    on first sight and cached per VIEW.
+
+    Key of a view: `view_ids[b]` when the caller names its views, else a content fingerprint of the view's map, so that the
+    anonymous, freshly collated tensors a DataLoader yields (new address every iteration, MyDataset.py:199-204) still find
+    their index. A resident tensor that is passed again (same address and version) skips the fingerprint.
+
+    A caller-named id is only as good as the caller's naming: ids must be unique per (scene, split, resolution) - use
+    tuples like (map_dir, i), as load_view_indices / load_view_maps do; a bare int reused for another split would name
+    another view's index. What IS checked: image size and table size on every use (a mismatch raises instead of reading
+    out of bounds), and the index's stored fingerprint against the map the first time an id is used with a map at hand."""
     Ns = int(Ns)
+    views = list(wi) if isinstance(wi, (list, tuple)) else [wi[b] for b in range(wi.shape[0])]
     if view_ids is not None:
-        keys = [('id', v if isinstance(v, (str, bytes, tuple)) else int(v), Ns) for v in view_ids]
-        if len(keys) != wi.shape[0]:
+        keys = [_view_key(v, Ns) for v in view_ids]
+        if len(keys) != len(views):
             raise ValueError('view_ids must name every view of the batch')
     else:
-        # identity shortcut: only for the very same tensor OBJECT (weak reference). An address alone proves nothing - the
-        # allocator hands a freed batch tensor's memory to the next one, with other views in it.
-        ident = (wi.data_ptr(), wi._version, tuple(wi.shape))
-        hit = _BATCH_KEYS.get(ident)
-        keys = hit[1] if hit is not None and hit[0]() is wi else None
-        if keys is None:
-            keys = [k + (Ns,) for k in fingerprints(wi)]
-            if len(_BATCH_KEYS) >= 64:
-                _BATCH_KEYS.clear()
-            _BATCH_KEYS[ident] = (weakref.ref(wi), keys)
+        if isinstance(wi, torch.Tensor):
+            # identity shortcut: only for the very same tensor OBJECT (weak reference). An address alone proves nothing - the
+            # allocator hands a freed batch tensor's memory to the next one, with other views in it.
+            ident = (wi.data_ptr(), wi._version, tuple(wi.shape))
+            hit = _BATCH_KEYS.get(ident)
+            keys = hit[1] if hit is not None and hit[0]() is wi else None
+            if keys is None:
+                keys = [k + (Ns,) for k in fingerprints(wi)]
+                if len(_BATCH_KEYS) >= 64:
+                    _BATCH_KEYS.clear()
+                _BATCH_KEYS[ident] = (weakref.ref(wi), keys)
+        else:
+            keys = [fingerprints(v.unsqueeze(0))[0] + (Ns,) for v in views]
     out = []
     for b, key in enumerate(keys):
+        wv = views[b]
+        P = int(wv.shape[-3] * wv.shape[-2]) if wv is not None else None
         vi = _VIEW_CACHE.pop(key, None)
         if vi is None:
-            vi = ViewIndex(wi[b], Ns)
+            if wv is None:
+                raise KeyError('view %r has neither a cached index nor a map to build one from' % (key,))
+            vi = ViewIndex(wv, Ns)
             total = sum(v.nbytes() for v in _VIEW_CACHE.values()) + vi.nbytes()
             while _VIEW_CACHE and total > VIEW_CACHE_BYTES:
                 total -= _VIEW_CACHE.pop(next(iter(_VIEW_CACHE))).nbytes()
+        else:
+            if vi.Ns != Ns or (P is not None and vi.P != P):
+                _VIEW_CACHE[key] = vi
+                raise ValueError('cached index of view %r was built for %d pixels / %d table rows, this call has %s / %d: the id '
+                                 'names another view (ids must be unique per scene, split and resolution)' % (key, vi.P, vi.Ns, P, Ns))
+            if key[0] == 'id' and not vi.verified and wv is not None and wv.is_cuda:
+                fp = fingerprints(wv.unsqueeze(0))[0]        # once per id: one 0.1 ms kernel
+                if vi.fp is not None and tuple(vi.fp) != tuple(fp):
+                    _VIEW_CACHE[key] = vi
+                    raise ValueError('the index registered for view %r was built from a different map (fingerprint mismatch): '
+                                     'stale sidecar or a reused id' % (key,))
+                vi.fp, vi.verified = fp, True
         _VIEW_CACHE[key] = vi
         out.append(vi)
     return out
 
 
+def _file_sig(path):
+    st = os.stat(path)
+    return (int(st.st_mtime_ns), int(st.st_size))
+
+
 def load_view_indices(map_dir, ids, Ns, save_missing=True):
     """Per-view indices stored next to the maps they belong to: for every i in `ids` loads
-    `<map_dir>/<i>.idx.pth` (ViewIndex.save) or, if it is not there yet, builds it from `<map_dir>/<i>.pth` (the float32
-    [2,H,W,8] weight / index map dist_to_weight writes, DW:95-97) and stores it. The indices are registered in the cache;
-    returns the view ids to hand to gauss_net.forward / nerfail_s_step (`view_ids=`), which then neither fingerprint nor
-    rebuild anything, whatever batches the DataLoader composes."""
-    import os
+    `<map_dir>/<i>.idx.pth` (ViewIndex.save) or, if it is not there yet - or was built from another version of the map
+    (the sidecar records the map file's mtime and size, and the map's fingerprint) - builds it from `<map_dir>/<i>.pth`
+    (the float32 [2,H,W,8] weight / index map dist_to_weight writes, DW:95-97) and stores it. The indices are registered
+    in the cache; returns the view ids to hand to gauss_net.forward / nerfail_s_step (`view_ids=`), which then neither
+    fingerprint nor rebuild anything, whatever batches the DataLoader composes."""
     out = []
     for i in ids:
         vid = (os.path.abspath(map_dir), int(i))
         side = os.path.join(map_dir, '%d.idx.pth' % int(i))
+        mpath = os.path.join(map_dir, '%d.pth' % int(i))
+        vi = None
         if os.path.exists(side):
             vi = ViewIndex.load(side)
             if vi.Ns != int(Ns):
                 raise ValueError('%s was built for a table of %d rows, not %d' % (side, vi.Ns, int(Ns)))
-        else:
-            wi = _lib.f32c(torch.load(os.path.join(map_dir, '%d.pth' % int(i)), map_location='cpu'), _cuda())
+            if os.path.exists(mpath) and (vi.src is None or tuple(vi.src) != _file_sig(mpath)):
+                vi = None                   # the map was regenerated (another c, another NeRF, another resolution): rebuild
+        if vi is None:
+            wi = _lib.f32c(torch.load(mpath, map_location='cpu'), _cuda())
             vi = ViewIndex(wi, int(Ns))
+            vi.src = _file_sig(mpath)
             if save_missing:
                 vi.save(side)
-        register_view_index(vid, vi, Ns)
+        register_view_index(vid, vi, Ns, replace=True)
         out.append(vid)
     return out
 
 
-def register_view_index(view_id, index, Ns=None):
-    """Put a ViewIndex loaded from disk (ViewIndex.load) into the cache under the caller's view id."""
-    _VIEW_CACHE[('id', view_id if isinstance(view_id, (str, bytes, tuple)) else int(view_id), int(Ns or index.Ns))] = index
+def register_view_index(view_id, index, Ns=None, replace=False):
+    """Put a ViewIndex loaded from disk (ViewIndex.load) into the cache under the caller's view id. An id that is already
+    taken by an index of ANOTHER map (different fingerprint or size) is refused unless replace=True."""
+    key = _view_key(view_id, Ns or index.Ns)
+    old = _VIEW_CACHE.get(key)
+    if old is not None and not replace and old is not index and (
+            old.P != index.P or (old.fp is not None and index.fp is not None and tuple(old.fp) != tuple(index.fp))):
+        raise ValueError('view id %r already names the index of another map; pass replace=True to overwrite it' % (view_id,))
+    _VIEW_CACHE[key] = index
+
+
+# ---------------------------------------------------------------------------------------------- device-resident views
+# The reference's dataset hands the attack loop a freshly loaded map per view and step (MyDataset.py:199-204: torch.load of
+# 41 MB + a cv2.imread per view; AS:304-317 passes them straight to the net): 8 x 51 MB over PCIe per iteration would be
+# ~20x the 0.35 ms gauss path. A view's map and image never change, so they are kept on the device BY VIEW ID (288 GB of
+# HBM hold a whole 400-view scene: 16 GB of maps + 1 GB of uint8 images): a forward that names its views finds them here
+# and ignores the tensors it was handed.
+_VIEW_MAPS = {}                      # key -> [2,H,W,8] float32 device tensor, insertion order = LRU order
+_VIEW_ORI = {}                       # key -> [H,W,4] uint8 (or float32) device tensor
+VIEW_MAPS_BYTES = 96 << 30
+
+
+def _lru_put(store, key, t, budget):
+    store.pop(key, None)
+    total = sum(v.numel() * v.element_size() for v in store.values()) + t.numel() * t.element_size()
+    while store and total > budget:
+        k0 = next(iter(store))
+        total -= store[k0].numel() * store[k0].element_size()
+        del store[k0]
+    store[key] = t
+
+
+def register_view(view_id, Ns, weight_and_index=None, ori_img=None):
+    """Keep a view's [2,H,W,8] map and / or its image (uint8 BGRA as the dataset reads it, or float) on the device under
+    `view_id`. Also builds (or verifies) the view's inverted index."""
+    key = _view_key(view_id, Ns)
+    dev = _cuda()
+    if weight_and_index is not None:
+        wi = _lib.f32c(torch.as_tensor(weight_and_index), dev)
+        if wi.dim() != 4 or wi.shape[0] != 2 or wi.shape[3] != 8:
+            raise ValueError('a view map must be [2,H,W,8] (DW:95-97)')
+        view_indices([wi], Ns, [view_id])
+        _lru_put(_VIEW_MAPS, key, wi, VIEW_MAPS_BYTES)
+    if ori_img is not None:
+        o = torch.as_tensor(ori_img)
+        o = o.to(dev).contiguous() if o.dtype == torch.uint8 else _lib.f32c(o, dev)
+        _lru_put(_VIEW_ORI, key, o, VIEW_MAPS_BYTES)
+    return key
+
+
+def load_view_maps(map_dir, ids, Ns, images=None):
+    """Device-resident maps for the attack loop: `<map_dir>/<i>.pth` of every i in `ids` is loaded ONCE,
+    kept on the device under the same ids load_view_indices uses, its inverted index loaded / built alongside. `images`:
+    optional {i: uint8 [H,W,4] array} (the cv2.imread result of MyDataset.py:200) kept resident too. Returns the view ids
+    for gauss_net.forward / nerfail_s_step (`view_ids=`)."""
+    vids = load_view_indices(map_dir, ids, Ns)
+    for i, vid in zip(ids, vids):
+        key = _view_key(vid, Ns)
+        if key not in _VIEW_MAPS:
+            wi = _lib.f32c(torch.load(os.path.join(map_dir, '%d.pth' % int(i)), map_location='cpu'), _cuda())
+            vi = _VIEW_CACHE[key]
+            if vi.P != wi.shape[1] * wi.shape[2]:
+                raise ValueError('%s/%d.pth does not match its index (pixels %d vs %d)' % (map_dir, int(i), wi.shape[1] * wi.shape[2], vi.P))
+            _lru_put(_VIEW_MAPS, key, wi, VIEW_MAPS_BYTES)
+        if images is not None and i in images:
+            register_view(vid, Ns, ori_img=images[i])
+    return vids
+
+
+class BatchViews:
+    """The views of one forward, one entry per view: device map [2,H,W,8], device image ([H,W,4] uint8 or float32), key.
+    Built by gauss_net.resolve_views from what the caller passed and what is resident."""
+
+    def __init__(self, wi, ori, ori_u8, view_ids, Ns, batch_wi=None, batch_ori=None):
+        self.wi, self.ori, self.ori_u8, self.view_ids, self.Ns = wi, ori, ori_u8, view_ids, Ns
+        self.batch_wi, self.batch_ori = batch_wi, batch_ori           # the contiguous batch tensors, when they came that way
+        self.B = len(wi)
+        self.H, self.W = int(wi[0].shape[1]), int(wi[0].shape[2])
+        self.P = self.H * self.W
+
+    def table(self):
+        t = (_lib.ViewFwdStruct * self.B)()
+        for b in range(self.B):
+            t[b].weight_and_index, t[b].ori_img = self.wi[b].data_ptr(), self.ori[b].data_ptr()
+        return t
+
+    def indices(self):
+        return view_indices(self.batch_wi if (self.batch_wi is not None and self.view_ids is None) else self.wi, self.Ns, self.view_ids)
+
+    def ori_float(self):
+        """[B,H,W,4] float32 (GN:55), materialised only when somebody needs it."""
+        if self.batch_ori is not None and self.batch_ori.dtype == torch.float32:
+            return self.batch_ori
+        return torch.stack([o.float() for o in self.ori])
+
+    def wi_batch(self):
+        return self.batch_wi if self.batch_wi is not None else torch.stack(self.wi)
+
+
+def resolve_views(spatial_rgb, weight_and_index_list, ori_img, view_ids=None, keep_resident=False):
+    """What the kernels will read for this batch. With `view_ids`, a view whose map / image is resident (load_view_maps,
+    register_view, or an earlier call with keep_resident) is taken from the device and the passed tensor is NOT touched -
+    the reference-shaped loop hands over CPU tensors from a DataLoader every iteration."""
+    dev = _cuda()
+    Ns = int(spatial_rgb.numel() // 4)
+    wi_in, ori_in = weight_and_index_list, ori_img
+    B = len(view_ids) if view_ids is not None else wi_in.shape[0]
+    keys = [_view_key(v, Ns) for v in view_ids] if view_ids is not None else [None] * B
+    res_wi = [_VIEW_MAPS.get(k) if k is not None else None for k in keys]
+    res_ori = [_VIEW_ORI.get(k) if k is not None else None for k in keys]
+    batch_wi = batch_ori = None
+    if any(w is None for w in res_wi):
+        if wi_in is None:
+            raise KeyError('a view of the batch is not resident and no weight_and_index_list was passed')
+        if not isinstance(wi_in, torch.Tensor) or wi_in.dim() != 5 or wi_in.shape[1] != 2 or wi_in.shape[4] != 8:
+            raise ValueError('weight_and_index_list must be [B,2,H,W,8] (DW:95-97)')
+        if all(w is None for w in res_wi):
+            # (a tensor already resident keeps its identity -> inverted-index cache hit)
+            batch_wi = wi_in if (wi_in.is_cuda and wi_in.dtype == torch.float32 and wi_in.is_contiguous()) else _lib.f32c(wi_in, dev)
+            res_wi = [batch_wi[b] for b in range(B)]
+        else:
+            res_wi = [w if w is not None else _lib.f32c(wi_in[b], dev) for b, w in enumerate(res_wi)]
+        if keep_resident and view_ids is not None:
+            for b, k in enumerate(keys):
+                if k not in _VIEW_MAPS:
+                    _lru_put(_VIEW_MAPS, k, res_wi[b].clone() if batch_wi is not None else res_wi[b], VIEW_MAPS_BYTES)
+    if any(o is None for o in res_ori):
+        o_in = torch.as_tensor(ori_in)
+        if o_in.dim() != 4 or o_in.shape[0] != B or o_in.shape[-1] != 4:
+            raise ValueError('ori_img must be [B,H,W,4] with the B of the batch, got %s' % (tuple(o_in.shape),))
+        if all(o is None for o in res_ori) and o_in.dtype != torch.uint8:
+            batch_ori = _lib.f32c(o_in, dev)                                               # GN:55
+            res_ori = [batch_ori[b] for b in range(B)]
+        else:
+            up = o_in.to(dev).contiguous() if o_in.dtype == torch.uint8 else _lib.f32c(o_in, dev)
+            res_ori = [o if o is not None else up[b] for b, o in enumerate(res_ori)]
+        if keep_resident and view_ids is not None:
+            for b, k in enumerate(keys):
+                if k not in _VIEW_ORI:
+                    _lru_put(_VIEW_ORI, k, res_ori[b].clone(), VIEW_MAPS_BYTES)
+    kinds = {o.dtype for o in res_ori}
+    if len(kinds) > 1:                                       # mixed uint8 / float images: one format for the kernel
+        res_ori = [o.float() for o in res_ori]
+        batch_ori = None
+    H, W = res_wi[0].shape[1], res_wi[0].shape[2]
+    for w, o in zip(res_wi, res_ori):
+        # the kernels index ori / x as [B*H*W] pixels and the table as float4[Ns]: mismatched shapes would read out of bounds
+        if tuple(w.shape) != (2, H, W, 8) or tuple(o.shape) != (H, W, 4):
+            raise ValueError('ori_img must be [B,H,W,4] with the B, H, W of weight_and_index_list, got %s vs %s' % (tuple(o.shape), tuple(w.shape)))
+    return BatchViews(res_wi, res_ori, res_ori[0].dtype == torch.uint8, view_ids, Ns, batch_wi, batch_ori)
+
+
+def hot_forward(spatial_rgb, views, epsilon=None, eps_minmax=None, need_x=True, need_aux=False):
+    """K10 over a BatchViews: (x or None, x_rgba, (aux_alpha, aux_mask) or None); no autograd."""
+    dev = _cuda()
+    s = _lib.f32c(spatial_rgb, dev).reshape(-1, 4)
+    B, H, W = views.B, views.H, views.W
+    x = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev) if need_x else None
+    x_rgba = torch.empty((B, H, W, 4), dtype=torch.float32, device=dev)
+    aux = (torch.empty((B, H, W), dtype=torch.float32, device=dev), torch.empty((B, H, W), dtype=torch.uint8, device=dev)) if need_aux else None
+    eps = -1.0 if epsilon is None else float(epsilon)
+    _lib.check(_lib.load().nerfail_gauss_fwd_views(_lib.dev(s, 'spatial_rgb'), s.shape[0], views.table(), B, views.P, int(views.ori_u8), eps,
+                                                   _lib.dev(x), _lib.dev(x_rgba), _lib.dev(aux[0]) if aux else None,
+                                                   _lib.dev(aux[1]) if aux else None, _lib.dev(eps_minmax), _lib.stream()))
+    return x, x_rgba, aux
+
+
+def hot_backward_rgb(aux, grad_x_rgba, views, out=None):
+    """K11, rgb-gradient-only form: d/d(spatial rgb) as [Ns,3] (flat buffer `out` of >= 3 Ns floats, e.g. with a tail slot
+    for the loss so that ONE all-reduce moves both)."""
+    dev = grad_x_rgba.device
+    Ns = views.Ns
+    vis = views.indices()
+    table, floats = view_table(vis)
+    scratch = torch.empty((floats,), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((3 * Ns,), dtype=torch.float32, device=dev)
+    gr = _lib.f32c(grad_x_rgba)
+    _lib.check(_lib.load().nerfail_gauss_bwd_views_rgb(_lib.dev(aux[0]), _lib.dev(aux[1]), _lib.dev(gr), table, views.B, Ns, views.P,
+                                                       _lib.dev(scratch), _lib.dev(out), _lib.stream()))
+    return out
 
 
 class _GaussGather(torch.autograd.Function):
-    """x, x_rgba = f(spatial_rgb); d/d(spatial_rgb) by the hand-written backward. weight/index/ori carry no grad.
+    """x, x_rgba = f(spatial_rgb); d/d(spatial_rgb) by the hand-written backward. The views carry no grad.
 
-    deterministic=True : gather-reduce over the cached inverted index (no atomics, bitwise reproducible).
+    deterministic=True : gather-reduce over the cached per-view inverted indices (no atomics, bitwise reproducible).
     deterministic=False: scatter with float atomics (nerfail_gauss_bwd; no setup, order-dependent last bits)."""
 
     @staticmethod
-    def forward(ctx, spatial, wi, ori, epsilon, eps_minmax, deterministic, view_ids=None):
-        dev = spatial.device
-        s = _lib.f32c(spatial).reshape(-1, 4)
-        B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
-        x = torch.empty(tuple(ori.shape), dtype=torch.float32, device=dev)
-        x_rgba = torch.empty(tuple(ori.shape), dtype=torch.float32, device=dev)
-        eps = -1.0 if epsilon is None else float(epsilon)
-        _lib.check(_lib.load().nerfail_gauss_fwd(_lib.dev(s, 'spatial_rgb'), s.shape[0], _lib.dev(wi, 'weight_and_index'),
-                                                 _lib.dev(ori, 'ori_img'), B, P, eps, _lib.dev(x), _lib.dev(x_rgba),
-                                                 _lib.dev(eps_minmax), _lib.stream()))
-        ctx.save_for_backward(wi, ori, x)
-        ctx.eps = eps
+    def forward(ctx, spatial, views, epsilon, eps_minmax, deterministic):
+        x, x_rgba, _ = hot_forward(spatial, views, epsilon, eps_minmax, need_x=True)
+        ctx.save_for_backward(x)
+        ctx.views = views
+        ctx.eps = -1.0 if epsilon is None else float(epsilon)
         ctx.s_shape = tuple(spatial.shape)
         ctx.deterministic = bool(deterministic)
-        ctx.view_ids = view_ids
         return x, x_rgba
 
     @staticmethod
     def backward(ctx, grad_x, grad_x_rgba):
-        wi, ori, x = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
+        views = ctx.views
         lib = _lib.load()
-        B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
+        B, P = views.B, views.P
         n = 1
         for d in ctx.s_shape[:-1]:
             n *= d
         gx = _lib.f32c(grad_x) if grad_x is not None else None
         gr = _lib.f32c(grad_x_rgba) if grad_x_rgba is not None else None
+        ori = views.ori_float()
         if ctx.deterministic:
             # every view reduced over its own index, the views' row sums added in view order (fixed order: bitwise
             # reproducible whatever else is in the cache)
             gs = torch.empty((n, 4), dtype=torch.float32, device=x.device)
-            vis = view_indices(wi, n, ctx.view_ids)
-            table, floats = view_table(vis)
+            table, floats = view_table(views.indices())
             scratch = torch.empty((floats,), dtype=torch.float32, device=x.device)
             _lib.check(lib.nerfail_gauss_bwd_views(_lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr), table, B, n, P,
                                                    ctx.eps, _lib.dev(scratch), _lib.dev(gs), _lib.stream()))
         else:
             gs = torch.zeros((n, 4), dtype=torch.float32, device=x.device)
-            _lib.check(lib.nerfail_gauss_bwd(_lib.dev(wi), _lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr),
+            _lib.check(lib.nerfail_gauss_bwd(_lib.dev(views.wi_batch()), _lib.dev(ori), _lib.dev(x), _lib.dev(gx), _lib.dev(gr),
                                              n, B, P, ctx.eps, _lib.dev(gs), _lib.stream()))
-        return gs.reshape(ctx.s_shape), None, None, None, None, None, None
+        return gs.reshape(ctx.s_shape), None, None, None, None
 
 
 def gauss_gather(spatial_rgb, weight_and_index_list, ori_img, epsilon=None, eps_minmax=None, deterministic=True, view_ids=None):
     """Functional form of the hot part: returns (x, x_rgba), differentiable w.r.t. spatial_rgb. `view_ids` (optional):
-    stable names of the batch's views (dataset indices) - keys of the per-view inverted indices (see view_indices)."""
+    stable names of the batch's views (dataset indices) - keys of the per-view inverted indices (see view_indices) and of
+    the device-resident maps / images (load_view_maps, register_view)."""
     dev = _cuda()
-    wi = weight_and_index_list
-    if not (isinstance(wi, torch.Tensor) and wi.is_cuda and wi.dtype == torch.float32 and wi.is_contiguous()):
-        wi = _lib.f32c(wi, dev)          # (a tensor already resident keeps its identity -> inverted-index cache hit)
-    ori = _lib.f32c(ori_img, dev)
-    if wi.dim() != 5 or wi.shape[1] != 2 or wi.shape[4] != 8:
-        raise ValueError('weight_and_index_list must be [B,2,H,W,8] (DW:95-97)')
-    # the kernels index ori / x as float4[B*H*W] and the table as float4[Ns]: mismatched shapes would read out of bounds
-    if tuple(ori.shape) != (wi.shape[0], wi.shape[2], wi.shape[3], 4):
-        raise ValueError('ori_img must be [B,H,W,4] with the B, H, W of weight_and_index_list, got %s vs %s'
-                         % (tuple(ori.shape), tuple(wi.shape)))
     if spatial_rgb.dim() < 2 or spatial_rgb.shape[-1] != 4 or spatial_rgb.numel() == 0:
         raise ValueError('spatial_rgb must be [..., 4] (BGRA rows of the point set), got %s' % (tuple(spatial_rgb.shape),))
     if spatial_rgb.device != dev:
         spatial_rgb = spatial_rgb.to(dev)
-    return _GaussGather.apply(spatial_rgb, wi, ori, epsilon, eps_minmax, deterministic, view_ids)
+    views = resolve_views(spatial_rgb, weight_and_index_list, ori_img, view_ids)
+    return _GaussGather.apply(spatial_rgb, views, epsilon, eps_minmax, deterministic)
 
 
 class gauss_net(nn.Module):
@@ -299,6 +511,9 @@ class gauss_net(nn.Module):
         # layout and falls back to naive_conv_* kernels (17 ms per 8-view forward of the 800x800 victim CNN, 73 % of an
         # attack iteration). True: same values, copied to packed NCHW first (the layout torchvision models are tuned for).
         self.classifier_input_contiguous = True
+        # True: a view that is named (view_ids=) and not yet resident is kept on the device after its first upload - the
+        # reference-shaped loop (CPU tensors from a DataLoader every iteration) then pays PCIe once per view, not per step
+        self.keep_views_resident = False
         self._eps_minmax = None      # device-side running [min, max] of x_rgb*alpha (GN:89-103), read lazily
 
     # -- resize of the cold tail: torchvision if present (as the reference), else the same bilinear op in torch
@@ -337,46 +552,74 @@ class gauss_net(nn.Module):
         print("epsilon_3d_max: ", self.epsilon_3d_max)
 
     def forward(self, spatial_rgb, weight_and_index_list, ori_img, zero_init_mask: bool = False, view_ids=None):
-        ori_img = _lib.f32c(torch.as_tensor(ori_img), _cuda())           # GN:55
-        if not (isinstance(weight_and_index_list, torch.Tensor) and weight_and_index_list.is_cuda
-                and weight_and_index_list.dtype == torch.float32 and weight_and_index_list.is_contiguous()):
-            weight_and_index_list = _lib.f32c(weight_and_index_list, _cuda())
-        self._last_ori, self._last_wi = ori_img, weight_and_index_list   # for logit_gradients()
-        self._last_view_ids = view_ids
-        x, x_rgba = gauss_gather(spatial_rgb, weight_and_index_list, ori_img, self.epsilon,
-                                 self._mm() if self.update_epsilon_3d else None, self.deterministic, view_ids)
-        # ---- cold tail, GN:121-157 (stock PyTorch)
+        dev = _cuda()
+        if spatial_rgb.device != dev:
+            spatial_rgb = spatial_rgb.to(dev)
+        views = resolve_views(spatial_rgb, weight_and_index_list, ori_img, view_ids, self.keep_views_resident)
+        ori_img = views.ori_float()                                      # GN:55
+        self._last_views = views                                         # for logit_gradients()
+        self._last_ori = ori_img
+        x, x_rgba = _GaussGather.apply(spatial_rgb, views, self.epsilon, self._mm() if self.update_epsilon_3d else None,
+                                       self.deterministic)
+        cla, ori_cla = self.cold_tail(x_rgba, ori_img)
+        return x, x_rgba, cla, ori_img, ori_cla
+
+    def cold_tail(self, x_rgba, ori_img, ori_key=None):
+        """GN:121-157 (stock PyTorch): NHWC -> NCHW, white background, Resize, the classifier on the perturbed and on the
+        original images. `ori_img` may be a callable that yields the float images (only evaluated when their logits are
+        not cached); `ori_key`: cache key of the original images' logits (default: the tensor's identity)."""
         cla_x = x_rgba.transpose(2, 3).transpose(1, 2)
-        cla_ori_img = ori_img.transpose(2, 3).transpose(1, 2)
         cla_x_3channel = torch.where(cla_x[:, 3:4] > 0, cla_x[:, :3], torch.full_like(cla_x[:, :3], 255.))
-        cla_ori_img_3channel = torch.where(cla_ori_img[:, 3:4] > 0, cla_ori_img[:, :3],
-                                           torch.full_like(cla_ori_img[:, :3], 255.))
         if self.classifier_input_contiguous:
             cla_x_3channel = cla_x_3channel.contiguous()
-            cla_ori_img_3channel = cla_ori_img_3channel.contiguous()
-        if self.model_name == "my_model":
-            pass
-        elif self.model_name == "vit_b_16":
-            cla_x_3channel = self._resize(cla_x_3channel, 224)
-            cla_ori_img_3channel = self._resize(cla_ori_img_3channel, 224)
-        else:
-            cla_x_3channel = self._resize(cla_x_3channel, 299)
-            cla_ori_img_3channel = self._resize(cla_ori_img_3channel, 299)
+        size = None if self.model_name == "my_model" else (224 if self.model_name == "vit_b_16" else 299)
+        if size is not None:
+            cla_x_3channel = self._resize(cla_x_3channel, size)
         cla = self.model(cla_x_3channel)
+
+        def ori_logits(grad):
+            o = ori_img() if callable(ori_img) else ori_img
+            c = o.transpose(2, 3).transpose(1, 2)
+            c3 = torch.where(c[:, 3:4] > 0, c[:, :3], torch.full_like(c[:, :3], 255.))
+            if self.classifier_input_contiguous:
+                c3 = c3.contiguous()
+            if size is not None:
+                c3 = self._resize(c3, size)
+            if grad:
+                return self.model(c3), o
+            with torch.no_grad():
+                return self.model(c3), o
         if self.cache_ori_cla:
-            key = (ori_img.data_ptr(), ori_img._version, tuple(ori_img.shape))
-            ori_cla = self._ori_cla_cache.get(key)
+            if ori_key is None:
+                o = ori_img() if callable(ori_img) else ori_img
+                ori_key = (o.data_ptr(), o._version, tuple(o.shape))
+                ori_img = o
+            ori_cla = self._ori_cla_cache.get(ori_key)
             if ori_cla is None:
                 if len(self._ori_cla_cache) >= 64:
                     self._ori_cla_cache.clear()
-                with torch.no_grad():
-                    ori_cla = self.model(cla_ori_img_3channel)
-                self._ori_cla_cache[key] = ori_cla
-                self._ori_cla_keep = getattr(self, '_ori_cla_keep', [])[-63:] + [ori_img]   # keeps data_ptr from being recycled
+                ori_cla, o = ori_logits(False)
+                self._ori_cla_cache[ori_key] = ori_cla
+                self._ori_cla_keep = getattr(self, '_ori_cla_keep', [])[-63:] + [o]   # keeps data_ptr from being recycled
         else:
-            ori_cla = self.model(cla_ori_img_3channel)
-        return x, x_rgba, cla, ori_img, ori_cla
+            ori_cla, _ = ori_logits(True)
+        return cla, ori_cla
 
+    def attack_forward(self, spatial_rgb, weight_and_index_list, ori_img, view_ids=None):
+        """The forward of one NeRFail-S step (AS:317) without what that step never uses: no `x` tensor (GN:83), no float copy
+        of the images unless the original logits have to be computed, alpha + pass mask kept for the rgb-only backward.
+        Returns (x_rgba leaf with requires_grad, cla, ori_cla, views, aux); differentiate cla down to x_rgba with autograd,
+        then hot_backward_rgb(aux, x_rgba.grad, views)."""
+        dev = _cuda()
+        s = spatial_rgb.detach()
+        if s.device != dev:
+            s = s.to(dev)
+        views = resolve_views(s, weight_and_index_list, ori_img, view_ids, self.keep_views_resident)
+        _, x_rgba, aux = hot_forward(s, views, self.epsilon, self._mm() if self.update_epsilon_3d else None, need_x=False, need_aux=True)
+        x_rgba.requires_grad_(True)
+        key = ('ids', tuple(_view_key(v, views.Ns) for v in view_ids)) if view_ids is not None else None
+        cla, ori_cla = self.cold_tail(x_rgba, views.ori_float, ori_key=key)
+        return x_rgba, cla, ori_cla, views, aux
 
     # ---- all class-logit gradients of one forward in ONE pass over the inverted index (DeepFool, SURVEY 8f N1)
     def logit_gradients(self, spatial_rgb, weight_and_index_list, x, x_rgba, cla, classes):
@@ -400,10 +643,10 @@ class gauss_net(nn.Module):
             J = torch.autograd.grad(cla, x_rgba, grad_outputs=sel, retain_graph=True, is_grads_batched=True)[0]
         else:
             J = torch.stack([torch.autograd.grad(cla, x_rgba, grad_outputs=sel[i], retain_graph=True)[0] for i in range(C)])
-        wi = weight_and_index_list
-        B, P = wi.shape[0], wi.shape[2] * wi.shape[3]
+        views = self._last_views
+        B, P = views.B, views.P
         n = spatial_rgb.numel() // 4
-        vi = view_indices(wi, n, getattr(self, '_last_view_ids', None))[0]      # one view (batch 1): its per-view index
+        vi = views.indices()[0]                                                 # one view (batch 1): its per-view index
         J = _lib.f32c(J).reshape(C, B * P, 4)
         ori = _lib.f32c(self._last_ori)
         out = torch.empty((C, n, 4), dtype=torch.float32, device=J.device)

@@ -78,6 +78,9 @@ SIGNATURES = {
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),
+    'nerfail_gauss_fwd_views': (c_i, [c_p, c_i64, c_p, c_i, c_i64, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'nerfail_gauss_bwd_views_rgb': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i64, c_i64, c_p, c_p, c_p]),
+    'nerfail_igsm_step_rgb': (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p]),
     'nerfail_fingerprint': (c_i, [c_p, c_i64, c_i64, c_p, c_p]),
     'nerfail_gauss_csr_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i64, c_i64]),
     'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
@@ -103,6 +106,11 @@ SIGNATURES = {
 class ViewIndexStruct(ctypes.Structure):
     """struct nerfail_view_index (include/nerfail_hip.h)"""
     _fields_ = [('packed', c_p), ('w_sorted', c_p), ('chunk_ord', c_p), ('pos', c_p), ('n_entries', c_i64), ('n_rows', c_i64)]
+
+
+class ViewFwdStruct(ctypes.Structure):
+    """struct nerfail_view_fwd (include/nerfail_hip.h)"""
+    _fields_ = [('weight_and_index', c_p), ('ori_img', c_p)]
 
 
 class AdamTensor(ctypes.Structure):

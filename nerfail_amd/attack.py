@@ -48,6 +48,62 @@ def perturbation_grad(net, spatial, weight_and_index, ori_img, label, batch_tota
     return s.grad, loss.detach(), cla.detach()
 
 
+def igsm_step_rgb(spatial, grad_rgb, spatial_init, a=2.0, epsilon=32.0, targeted=False):
+    """AS:352-392 with the gradient as [Ns,3] (rgb only; the alpha channel's gradient is never read by the sign step)."""
+    dev = _cuda()
+    s, s0 = _lib.f32c(spatial, dev), _lib.f32c(spatial_init, dev)
+    n = s.numel() // 4
+    g = _lib.f32c(grad_rgb, dev)
+    if s.shape[-1] != 4 or s0.shape != s.shape or g.numel() < 3 * n:
+        raise ValueError('spatial / spatial_init must be [..., 4] of the same shape and grad_rgb hold 3 floats per row')
+    out = torch.empty_like(s)
+    _lib.check(_lib.load().nerfail_igsm_step_rgb(_lib.dev(s), _lib.dev(g), _lib.dev(s0), n, float(a), float(epsilon), int(bool(targeted)),
+                                                 _lib.dev(out), _lib.stream()))
+    return out
+
+
+def perturbation_grad_rgb(net, spatial, weight_and_index, ori_img, label, batch_total=None, view_ids=None, out=None):
+    """The NeRFail-S step's gradient in the form the step consumes (AS:357-392 reads grad[..., :3] only): a flat buffer of
+    3 Ns + 1 floats - d(CE)/d(spatial rgb) as [Ns,3], then the loss - filled by the rgb-only backward (no `x` tensor, 5 bytes
+    per pixel between forward and backward, 23 MB instead of 30.7 MB for the all-reduce, which carries the loss in the same
+    collective). The three channels equal perturbation_grad()'s bit for bit."""
+    from .GaussNet import hot_backward_rgb
+    xr, cla, ori_cla, views, aux = net.attack_forward(spatial, weight_and_index, ori_img, view_ids)
+    lab = label.to(cla.device).broadcast_to([cla.shape[0]])
+    loss = torch.nn.functional.cross_entropy(cla, lab, reduction='sum') / float(batch_total or cla.shape[0])
+    loss.backward()
+    Ns = views.Ns
+    if out is None:
+        out = torch.empty((3 * Ns + 1,), dtype=torch.float32, device=xr.device)
+    hot_backward_rgb(aux, xr.grad, views, out)
+    out[3 * Ns] = loss.detach()
+    return out, cla.detach()
+
+
+def sharded_perturbation_grad_rgb(net, spatial, weight_and_index, ori_img, label, group=None, timing=None, view_ids=None):
+    """perturbation_grad_rgb of this rank's share of the batch's views, then ONE all-reduce of the 3 Ns + 1 floats (C1: the
+    gradient and, in its tail, the loss). Identical on every rank."""
+    world, rank = sharding.world_and_rank(group)
+    B = len(view_ids) if view_ids is not None else weight_and_index.shape[0]
+    lo, hi = sharding.shard_range(B, rank, world)
+    Ns = spatial.numel() // 4
+    if hi > lo:
+        buf, _ = perturbation_grad_rgb(net, spatial, None if weight_and_index is None else weight_and_index[lo:hi],
+                                       None if ori_img is None else ori_img[lo:hi], label, batch_total=B,
+                                       view_ids=None if view_ids is None else list(view_ids)[lo:hi])
+    else:                                   # more ranks than views: this rank only takes part in the sum
+        buf = torch.zeros((3 * Ns + 1,), dtype=torch.float32, device=_cuda())
+    if world > 1:
+        if timing is not None and buf.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        sharding.all_reduce_sum_(buf, group)         # C1: the perturbation-gradient all-reduce (+ the loss in its tail)
+        if timing is not None and buf.is_cuda:
+            e1.record()
+            timing.setdefault('allreduce_events', []).append((e0, e1, buf.numel() * buf.element_size()))
+    return buf
+
+
 def sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group=None, timing=None, view_ids=None):
     """d(mean CE over the WHOLE batch)/d(spatial), identical on every rank: this rank differentiates its contiguous
     share of the batch's views (weight k/B), then ONE all-reduce sums the [P,H,W,4] gradient (C1).
@@ -77,6 +133,10 @@ def nerfail_s_step(net, spatial, spatial_init, weight_and_index, ori_img, label,
                    targeted=False, group=None, timing=None, view_ids=None):
     """One NeRFail-S iteration (AS:304-392) on one batch of views. Sharded over ranks when torch.distributed is up:
     every rank ends with the identical perturbation tensor."""
+    if getattr(net, 'deterministic', True) and getattr(net, 'rgb_grad_only', True):
+        Ns = spatial.numel() // 4
+        buf = sharded_perturbation_grad_rgb(net, spatial, weight_and_index, ori_img, label, group, timing, view_ids)
+        return igsm_step_rgb(spatial, buf, spatial_init, a, epsilon, targeted), buf[3 * Ns]
     g, loss = sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, group, timing, view_ids)
     return igsm_step(spatial, g, spatial_init, a, epsilon, targeted), loss
 

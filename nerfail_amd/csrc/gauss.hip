@@ -55,8 +55,10 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
 }
 
 // x -> (x, x_rgba) of one pixel and the epsilon bookkeeping (GN:85-119)
+// `mask`: bit c set <=> d x_rgba_c / d (x_c * alpha) = 1, i.e. the pixel is opaque and channel c is inside both clips - all the
+// backward needs besides alpha when only the rgb gradient is wanted (same comparisons as gauss_pixel_grad_kernel).
 __device__ __forceinline__ void finish_pixel(const float4 x, const float4 o, const float epsilon, float& emin, float& emax,
-                                             float4& x_out, float4& x_rgba) {
+                                             float4& x_rgba, float& alpha_out, unsigned& mask) {
     const float alpha = __fdiv_rn(x.w, 255.0f);
     float dlt[3] = {__fmul_rn(x.x, alpha), __fmul_rn(x.y, alpha), __fmul_rn(x.z, alpha)};
     if (alpha > 0.f) {                // GN:89-103 bookkeeping uses where(alpha>0, x, 0) * alpha
@@ -65,14 +67,22 @@ __device__ __forceinline__ void finish_pixel(const float4 x, const float4 o, con
     }
     float rgb[3];
     const float oc[3] = {o.x, o.y, o.z};
+    mask = 0u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float d = dlt[c];
-        if (epsilon >= 0.f) d = fminf(fmaxf(d, -epsilon), epsilon);
-        float v = (o.w > 0.f) ? __fadd_rn(oc[c], d) : 0.f;
+        bool pass = o.w > 0.f;
+        if (epsilon >= 0.f) {
+            pass = pass && (d >= -epsilon) && (d <= epsilon);     // clip backward passes inside [min, max] inclusive
+            d = fminf(fmaxf(d, -epsilon), epsilon);
+        }
+        const float pre = __fadd_rn(oc[c], d);
+        pass = pass && (pre >= 0.f) && (pre <= 255.f);
+        mask |= pass ? (1u << c) : 0u;
+        const float v = (o.w > 0.f) ? pre : 0.f;
         rgb[c] = fminf(fmaxf(v, 0.f), 255.f);
     }
-    x_out = x;
+    alpha_out = alpha;
     x_rgba = make_float4(rgb[0], rgb[1], rgb[2], fminf(fmaxf(o.w, 0.f), 255.f));
 }
 
@@ -92,23 +102,47 @@ __device__ __forceinline__ void fold_minmax(float emin, float emax, float* __res
     }
 }
 
-__global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict__ spatial, long Ns,
-                                                        const float* __restrict__ wi, const float4* __restrict__ ori,
-                                                        long B, long P, float epsilon, float4* __restrict__ x_out,
-                                                        float4* __restrict__ x_rgba, float* __restrict__ eps_minmax) {
+// Views are addressed through a pointer table (kernel argument): a batch tensor [B,2,P,8] is B consecutive entries, the
+// device-resident maps of the attack loop (one tensor per view, kept by view id) are whatever the cache holds. One
+// workgroup never straddles two views, so its table entry is a scalar load. ORI_U8: ori_img as the uint8 BGRA the
+// reference's dataset reads (cv2.imread, MyDataset.py:200) - 4 bytes per pixel instead of 16.
+// Outputs besides x_rgba are optional: x (GN:83; the first element of gauss_net's return tuple) and, for the
+// rgb-gradient-only backward of the NeRFail-S step, alpha = x_3 / 255 plus the 3-bit pass mask (5 bytes per pixel
+// instead of re-reading x and ori: 32).
+constexpr int kFwdViews = 16;
+struct FwdViews {
+    const float* wi[kFwdViews];
+    const void* ori[kFwdViews];
+    int nv;
+};
+
+template <bool ORI_U8>
+__global__ __launch_bounds__(256) void gauss_fwd_views_kernel(const float4* __restrict__ spatial, long Ns, FwdViews tab, long P,
+                                                              int bpv, float epsilon, float4* __restrict__ x_out,
+                                                              float4* __restrict__ x_rgba, float* __restrict__ aux_alpha,
+                                                              unsigned char* __restrict__ aux_mask, float* __restrict__ eps_minmax) {
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 picks the XCD, each with its own L2). Neighbouring
     // pixels gather neighbouring rows of the table, so every XCD gets ONE contiguous eighth of the pixel range instead of
     // every eighth workgroup: a row fetched into an L2 serves the whole neighbourhood from there.
     const long per = gridDim.x >> 3;                                           // (the grid is a multiple of 8 workgroups)
     const long vb = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);          // virtual block: [xcd][position in its eighth]
-    const long g = vb * blockDim.x + threadIdx.x;
+    const int v = (int)(vb / bpv);                                             // wave-uniform
+    const long p = (vb - (long)v * bpv) * blockDim.x + threadIdx.x;
     float emin = 0.f, emax = 0.f;   // the running values start at 0 (GN:27-28), so 0 is neutral
-    if (g < B * P) {
-        const long b = g / P, p = g - b * P;
-        const float4* w4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 0) * P + p) * 8);
-        const float4* i4 = reinterpret_cast<const float4*>(wi + ((b * 2 + 1) * P + p) * 8);
+    if (v < tab.nv && p < P) {
+        const float* __restrict__ wi = tab.wi[v];
+        const long g = (long)v * P + p;
+        const float4* w4 = reinterpret_cast<const float4*>(wi + p * 8);
+        const float4* i4 = reinterpret_cast<const float4*>(wi + (P + p) * 8);
         const float4 wa = w4[0], wb = w4[1];
         const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        float4 o;
+        if (ORI_U8) {
+            const uchar4 u = reinterpret_cast<const uchar4*>(tab.ori[v])[p];
+            o = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+        } else {
+            o = reinterpret_cast<const float4*>(tab.ori[v])[p];
+        }
         // a background pixel (60 % of a real view): all 8 weights are 0 (GN:181) - neither its indices nor any row is read
         const bool any = (wa.x != 0.f) | (wa.y != 0.f) | (wa.z != 0.f) | (wa.w != 0.f) | (wb.x != 0.f) | (wb.y != 0.f) | (wb.z != 0.f) | (wb.w != 0.f);
         float4 rows[8];
@@ -132,7 +166,13 @@ __global__ __launch_bounds__(256) void gauss_fwd_kernel(const float4* __restrict
             x.z = __fadd_rn(x.z, __fmul_rn(rows[k].z, w[k]));
             x.w = __fadd_rn(x.w, __fmul_rn(rows[k].w, w[k]));
         }
-        finish_pixel(x, ori[g], epsilon, emin, emax, x_out[g], x_rgba[g]);
+        float alpha;
+        unsigned mask;
+        float4 xr;
+        finish_pixel(x, o, epsilon, emin, emax, xr, alpha, mask);
+        x_rgba[g] = xr;
+        if (x_out != nullptr) x_out[g] = x;
+        if (aux_alpha != nullptr) { aux_alpha[g] = alpha; aux_mask[g] = (unsigned char)mask; }
     }
     fold_minmax(emin, emax, eps_minmax);
 }
@@ -213,6 +253,38 @@ __global__ __launch_bounds__(256) void igsm_step_kernel(const float4* __restrict
     out[g] = make_float4(r[0], r[1], r[2], v.w);
 }
 
+// the same with the gradient as [n,3] (rgb only: AS:357-392 never reads the alpha channel's gradient)
+__global__ __launch_bounds__(256) void igsm_step_rgb_kernel(const float4* __restrict__ s, const float* __restrict__ grad3,
+                                                            const float4* __restrict__ s_init, long n, float a, float epsilon,
+                                                            int targeted, float4* __restrict__ out) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const float4 v = s[g], in = s_init[g];
+    const float sv[3] = {v.x, v.y, v.z}, gv[3] = {grad3[3 * g], grad3[3 * g + 1], grad3[3 * g + 2]}, iv[3] = {in.x, in.y, in.z};
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float sg = (gv[c] > 0.f) ? 1.f : ((gv[c] < 0.f) ? -1.f : 0.f);
+        const float st = __fmul_rn(a, sg);
+        float q = targeted ? __fsub_rn(sv[c], st) : __fadd_rn(sv[c], st);
+        q = (v.w > 0.f) ? q : 0.f;
+        q = fmaxf(q, __fsub_rn(iv[c], epsilon));
+        q = fminf(q, __fadd_rn(iv[c], epsilon));
+        r[c] = q;
+    }
+    out[g] = make_float4(r[0], r[1], r[2], v.w);
+}
+
+static int launch_fwd_views(const float4* spatial, long Ns, const FwdViews& tab, long P, bool ori_u8, float epsilon, float4* x,
+                            float4* x_rgba, float* aux_alpha, unsigned char* aux_mask, float* eps_minmax, hipStream_t s) {
+    const int bpv = (int)((P + 255) / 256);
+    const unsigned blocks = (unsigned)((((long)tab.nv * bpv + 7) / 8) * 8);
+    if (ori_u8) gauss_fwd_views_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(spatial, Ns, tab, P, bpv, epsilon, x, x_rgba, aux_alpha, aux_mask, eps_minmax);
+    else gauss_fwd_views_kernel<false><<<dim3(blocks), dim3(256), 0, s>>>(spatial, Ns, tab, P, bpv, epsilon, x, x_rgba, aux_alpha, aux_mask, eps_minmax);
+    NF_LAUNCHED("gauss_fwd_views_kernel");
+    return NERFAIL_OK;
+}
+
 }  // namespace nerfail
 
 using namespace nerfail;
@@ -234,10 +306,43 @@ extern "C" int nerfail_gauss_fwd(const float* spatial, int64_t Ns, const float* 
     if (B * P == 0) return NERFAIL_OK;
     NF_REQUIRE(spatial != nullptr && weight_and_index != nullptr && ori_img != nullptr, "NULL input pointer");
     NF_REQUIRE(x != nullptr && x_rgba != nullptr, "NULL output pointer");
-    gauss_fwd_kernel<<<dim3((unsigned)(((B * P + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, as_stream(stream)>>>(
-        (const float4*)spatial, Ns, weight_and_index, (const float4*)ori_img, B, P, epsilon, (float4*)x, (float4*)x_rgba,
-        eps_minmax);
-    NF_LAUNCHED("gauss_fwd_kernel");
+    for (int64_t b0 = 0; b0 < B; b0 += kFwdViews) {
+        FwdViews tab;
+        tab.nv = (int)(B - b0 < kFwdViews ? B - b0 : kFwdViews);
+        for (int i = 0; i < kFwdViews; ++i) {
+            const int64_t b = b0 + (i < tab.nv ? i : 0);
+            tab.wi[i] = weight_and_index + b * 2 * P * 8;
+            tab.ori[i] = ori_img + b * P * 4;
+        }
+        const int rc = launch_fwd_views((const float4*)spatial, Ns, tab, P, false, epsilon, (float4*)x + b0 * P, (float4*)x_rgba + b0 * P,
+                                        nullptr, nullptr, eps_minmax, as_stream(stream));
+        if (rc != NERFAIL_OK) return rc;
+    }
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_gauss_fwd_views(const float* spatial, int64_t Ns, const nerfail_view_fwd* views, int n_views, int64_t P,
+                                       int ori_is_u8, float epsilon, float* x, float* x_rgba, float* aux_alpha,
+                                       unsigned char* aux_mask, float* eps_minmax, void* stream) {
+    NF_REQUIRE(Ns > 0 && n_views >= 0 && P >= 0, "bad sizes");
+    if ((int64_t)n_views * P == 0) return NERFAIL_OK;
+    NF_REQUIRE(spatial != nullptr && views != nullptr && x_rgba != nullptr, "NULL pointer");
+    NF_REQUIRE((aux_alpha == nullptr) == (aux_mask == nullptr), "aux_alpha and aux_mask come together");
+    for (int v = 0; v < n_views; ++v) NF_REQUIRE(views[v].weight_and_index != nullptr && views[v].ori_img != nullptr, "a view has a NULL map or image");
+    for (int v0 = 0; v0 < n_views; v0 += kFwdViews) {
+        FwdViews tab;
+        tab.nv = n_views - v0 < kFwdViews ? n_views - v0 : kFwdViews;
+        for (int i = 0; i < kFwdViews; ++i) {
+            const nerfail_view_fwd& vw = views[v0 + (i < tab.nv ? i : 0)];
+            tab.wi[i] = vw.weight_and_index;
+            tab.ori[i] = vw.ori_img;
+        }
+        const int rc = launch_fwd_views((const float4*)spatial, Ns, tab, P, ori_is_u8 != 0, epsilon,
+                                        x ? (float4*)x + (int64_t)v0 * P : nullptr, (float4*)x_rgba + (int64_t)v0 * P,
+                                        aux_alpha ? aux_alpha + (int64_t)v0 * P : nullptr, aux_mask ? aux_mask + (int64_t)v0 * P : nullptr,
+                                        eps_minmax, as_stream(stream));
+        if (rc != NERFAIL_OK) return rc;
+    }
     return NERFAIL_OK;
 }
 
@@ -264,5 +369,16 @@ extern "C" int nerfail_igsm_step(const float* spatial, const float* grad, const 
     igsm_step_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
         (const float4*)spatial, (const float4*)grad, (const float4*)spatial_init, n, a, epsilon, targeted, (float4*)out);
     NF_LAUNCHED("igsm_step_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_igsm_step_rgb(const float* spatial, const float* grad_rgb, const float* spatial_init, int64_t n, float a,
+                                     float epsilon, int targeted, float* out, void* stream) {
+    NF_REQUIRE(n >= 0, "n is negative");
+    if (n == 0) return NERFAIL_OK;
+    NF_REQUIRE(spatial != nullptr && grad_rgb != nullptr && spatial_init != nullptr && out != nullptr, "NULL pointer");
+    igsm_step_rgb_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        (const float4*)spatial, grad_rgb, (const float4*)spatial_init, n, a, epsilon, targeted, (float4*)out);
+    NF_LAUNCHED("igsm_step_rgb_kernel");
     return NERFAIL_OK;
 }

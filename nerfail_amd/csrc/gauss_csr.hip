@@ -93,6 +93,27 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __r
     g_out[g] = gx;
 }
 
+// pass 1, rgb-gradient-only form (the NeRFail-S step: AS:357-392 never reads the alpha channel's gradient): from what the
+// forward left behind - alpha and the 3-bit pass mask, 5 bytes per pixel - instead of x and ori (32 bytes). Pixels whose
+// mask is 0 (background, saturated) read nothing else. The rgb values equal gauss_pixel_grad_kernel's bit for bit.
+__global__ __launch_bounds__(256) void gauss_pixel_grad_rgb_kernel(const float* __restrict__ aux_alpha,
+                                                                   const unsigned char* __restrict__ aux_mask,
+                                                                   const float4* __restrict__ grad_x_rgba, long n,
+                                                                   float4* __restrict__ g_out) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const unsigned m = aux_mask[g];
+    float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m != 0u) {
+        const float alpha = aux_alpha[g];
+        const float4 gr = grad_x_rgba[g];
+        gx.x = ((m & 1u) ? gr.x : 0.f) * alpha;
+        gx.y = ((m & 2u) ? gr.y : 0.f) * alpha;
+        gx.z = ((m & 4u) ? gr.z : 0.f) * alpha;
+    }
+    g_out[g] = gx;
+}
+
 // pass 2: grad_s[j] = sum over the entries of row j of w_e * g[pixel_e], as a SEGMENTED REDUCTION OVER ENTRIES.
 // Real maps have very uneven rows (a surface point seen at a grazing angle by a base view is the neighbour of thousands
 // of pixels of other views, most rows of background points have no entry at all): with one lane per row the longest
@@ -409,6 +430,20 @@ __global__ __launch_bounds__(256) void gauss_rows_sum_kernel(RowsSum a, long Ns,
     }
 }
 
+// the same sum written as [Ns,3] (rgb only): the buffer the perturbation-gradient all-reduce moves (23 MB instead of 30.7)
+__global__ __launch_bounds__(256) void gauss_rows_sum3_kernel(RowsSum a, long Ns, int accumulate, float* __restrict__ grad3) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ns) return;
+    int p[kViewsPerLaunch];
+#pragma unroll
+    for (int v = 0; v < kViewsPerLaunch; ++v) p[v] = v < a.nv ? a.pos[v][j] : -1;      // all index loads first
+    float4 s = accumulate ? make_float4(grad3[3 * j], grad3[3 * j + 1], grad3[3 * j + 2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int v = 0; v < kViewsPerLaunch; ++v)
+        if (p[v] >= 0) s = f4_add(s, a.val[v][p[v]]);
+    grad3[3 * j] = s.x; grad3[3 * j + 1] = s.y; grad3[3 * j + 2] = s.z;
+}
+
 // Row ordinals of a view index: pos[j] = number of non-empty rows before row j, or -1 for an empty row; n_rows = number
 // of non-empty rows (flags -> exclusive sum -> fix-up); then the packed entries and the per-chunk first ordinals.
 __global__ __launch_bounds__(256) void view_row_flags_kernel(const int* __restrict__ row_ptr, long Ns, int* __restrict__ flags) {
@@ -673,21 +708,11 @@ extern "C" size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_inde
     return f;
 }
 
-extern "C" int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
-                                       const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
-                                       float* scratch, float* grad_spatial, void* stream) {
-    NF_REQUIRE(Ns > 0 && P > 0 && n_views >= 1, "bad sizes");
-    NF_REQUIRE(ori_img && x && views && scratch && grad_spatial, "NULL pointer");
-    for (int v = 0; v < n_views; ++v)
-        NF_REQUIRE(view_ok(views[v], Ns, P), "a view index is incomplete or inconsistent (NULL array, n_entries > 8 P, n_rows > n_entries)");
-    hipStream_t s = as_stream(stream);
+// steps 2 + 3 of the batched backward: every view's entries -> its own row sums (one launch for up to 16 views), then the
+// views' sums added per row in view order, into [Ns,4] (grad4) or [Ns,3] (grad3)
+static int reduce_views(const nerfail_view_index* views, int n_views, long Ns, long P, float* scratch, float* grad4, float* grad3,
+                        hipStream_t s) {
     const long n = (long)n_views * P;
-    // 1. per-pixel gradients of the whole batch in one launch
-    gauss_pixel_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
-        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x, (const float4*)grad_x_rgba, n, epsilon,
-        (float4*)scratch);
-    NF_LAUNCHED("gauss_pixel_grad_kernel");
-    // 2. every view's entries -> its own row sums (one launch for up to 16 views); 3. the views' sums added per row
     float* cursor = scratch + (size_t)n * 4;
     for (int v0 = 0; v0 < n_views; v0 += kViewsPerLaunch) {
         SegViews a;
@@ -716,10 +741,47 @@ extern "C" int nerfail_gauss_bwd_views(const float* ori_img, const float* x, con
             gauss_seg_combine_views_kernel<<<dim3((unsigned)((max_chunks + 255) / 256), (unsigned)nv), dim3(256), 0, s>>>(a);
             NF_LAUNCHED("gauss_seg_combine_views_kernel");
         }
-        gauss_rows_sum_kernel<1><<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, (float4*)grad_spatial);
-        NF_LAUNCHED("gauss_rows_sum_kernel");
+        if (grad3 != nullptr) {
+            gauss_rows_sum3_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, grad3);
+            NF_LAUNCHED("gauss_rows_sum3_kernel");
+        } else {
+            gauss_rows_sum_kernel<1><<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, (float4*)grad4);
+            NF_LAUNCHED("gauss_rows_sum_kernel");
+        }
     }
     return NERFAIL_OK;
+}
+
+extern "C" int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* grad_x, const float* grad_x_rgba,
+                                       const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float epsilon,
+                                       float* scratch, float* grad_spatial, void* stream) {
+    NF_REQUIRE(Ns > 0 && P > 0 && n_views >= 1, "bad sizes");
+    NF_REQUIRE(ori_img && x && views && scratch && grad_spatial, "NULL pointer");
+    for (int v = 0; v < n_views; ++v)
+        NF_REQUIRE(view_ok(views[v], Ns, P), "a view index is incomplete or inconsistent (NULL array, n_entries > 8 P, n_rows > n_entries)");
+    hipStream_t s = as_stream(stream);
+    const long n = (long)n_views * P;
+    // 1. per-pixel gradients of the whole batch in one launch
+    gauss_pixel_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+        (const float4*)ori_img, (const float4*)x, (const float4*)grad_x, (const float4*)grad_x_rgba, n, epsilon,
+        (float4*)scratch);
+    NF_LAUNCHED("gauss_pixel_grad_kernel");
+    return reduce_views(views, n_views, Ns, P, scratch, grad_spatial, nullptr, s);
+}
+
+extern "C" int nerfail_gauss_bwd_views_rgb(const float* aux_alpha, const unsigned char* aux_mask, const float* grad_x_rgba,
+                                           const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float* scratch,
+                                           float* grad_rgb, void* stream) {
+    NF_REQUIRE(Ns > 0 && P > 0 && n_views >= 1, "bad sizes");
+    NF_REQUIRE(aux_alpha && aux_mask && grad_x_rgba && views && scratch && grad_rgb, "NULL pointer");
+    for (int v = 0; v < n_views; ++v)
+        NF_REQUIRE(view_ok(views[v], Ns, P), "a view index is incomplete or inconsistent (NULL array, n_entries > 8 P, n_rows > n_entries)");
+    hipStream_t s = as_stream(stream);
+    const long n = (long)n_views * P;
+    gauss_pixel_grad_rgb_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(aux_alpha, aux_mask, (const float4*)grad_x_rgba, n,
+                                                                                        (float4*)scratch);
+    NF_LAUNCHED("gauss_pixel_grad_rgb_kernel");
+    return reduce_views(views, n_views, Ns, P, scratch, nullptr, grad_rgb, s);
 }
 
 // ONE view, C right-hand sides over the view's compact index: reduce -> combine -> expand through pos

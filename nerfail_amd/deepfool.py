@@ -68,7 +68,7 @@ def deepfool(net_input, e, net, num_classes=8, max_iter=20, target_label: int = 
         if multi:
             # all class gradients in one pass over the inverted index (K11 multi-RHS), then the step arithmetic in two
             # streaming kernels (K14): ||G_k - G_o||^2 for every k, device-side choice, rot / clamp / alpha restore
-            G = net.logit_gradients(spatial_rgb, net._last_wi, x_out, x_rgba, cla, [o] + ks)
+            G = net.logit_gradients(spatial_rgb, None, x_out, x_rgba, cla, [o] + ks)
             lib = _lib.load()
             C, n = G.shape[0], G[0].numel() // 4
             nb = lib.nerfail_deepfool_norms_scratch_bytes(C, n)

@@ -1,4 +1,6 @@
 """-m gpu: gauss path (K9-K12) through the C ABI against the reference's golden vectors and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -350,3 +352,127 @@ def test_backward_of_more_views_than_one_launch_holds():
         return s.grad
     a, b, ref = grad(True), grad(True), grad(False)
     assert torch.equal(a, b) and rel_err(N(a), N(ref)) < 1e-4
+
+
+def _toy_attack(seed=21, B=5, P=3, H=14, W=12):
+    from nerfail_amd import GaussNet as G
+    rs = np.random.RandomState(seed)
+    s0 = rs.uniform(-40, 40, size=(P, H, W, 4)).astype(np.float32)
+    s0[..., 3] = np.where(rs.uniform(size=(P, H, W)) < 0.8, 255.0, 0.0)
+    ori_u8 = synth.disc_alpha_image(B, H, W, seed=seed + 1).astype(np.uint8)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    dist[:, :2] = 1.0                                                # some background rows (all weights 0)
+    idx = rs.randint(0, P * H * W, size=(B, H, W, 8)).astype(np.float32)
+    wi, _ = G.create_gauss_w(dev(), 0.02)(T(np.stack([dist, idx], 1)))
+    torch.manual_seed(seed)
+    victim = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(2), torch.nn.Flatten(),
+                                 torch.nn.Linear(16, 8)).to(dev()).requires_grad_(False)
+    return T(s0), wi, ori_u8, victim
+
+
+@pytest.mark.parametrize('eps', [None, 24.0])
+def test_rgb_only_attack_step_equals_the_full_gradient_path(eps):
+    """The NeRFail-S step reads grad[..., :3] only (AS:357-392). Its fast path (no x tensor, alpha + 3-bit mask between forward
+    and backward, gradient as [Ns,3] with the loss in the buffer's tail) must give the SAME BITS as the full autograd path:
+    the rgb gradient, the loss, and the updated perturbation."""
+    from nerfail_amd import GaussNet as G, attack as A
+    s0, wi, ori_u8, victim = _toy_attack()
+    ori = T(ori_u8.astype(np.float32))
+    label = torch.tensor(3, device=dev())
+    net = G.gauss_net(dev(), 0.02, victim, 'my_model', epsilon=eps)
+    g_full, loss_full, _ = A.perturbation_grad(net, s0, wi, ori, label)
+    buf, _ = A.perturbation_grad_rgb(net, s0, wi, ori, label)
+    Ns = s0.numel() // 4
+    assert torch.equal(buf[:3 * Ns].view(Ns, 3), g_full.reshape(Ns, 4)[:, :3].contiguous())
+    assert float(buf[3 * Ns]) == float(loss_full)
+    assert float(g_full.abs().max()) > 0
+    net.rgb_grad_only = False
+    s_a, l_a = A.nerfail_s_step(net, s0, s0, wi, ori, label, 2.0, 32.0, False)
+    net.rgb_grad_only = True
+    s_b, l_b = A.nerfail_s_step(net, s0, s0, wi, ori, label, 2.0, 32.0, False)
+    assert torch.equal(s_a, s_b) and float(l_a) == float(l_b)
+    # uint8 images (what cv2.imread hands the reference's dataset, MyDataset.py:200) give the same bits as their float copy
+    s_c, l_c = A.nerfail_s_step(net, s0, s0, wi, torch.from_numpy(ori_u8).to(dev()), label, 2.0, 32.0, False)
+    assert torch.equal(s_c, s_b) and float(l_c) == float(l_b)
+
+
+def test_views_resident_by_id_ignore_the_passed_host_tensors(tmp_path):
+    """the reference's loop hands the step CPU tensors from a DataLoader every iteration
+    (MyDataset.py:199-204, AS:304-317). Views named by id and resident on the device (load_view_maps / register_view /
+    keep_views_resident) are taken from there: same bits as the passed-tensor path, and the passed tensors are not read."""
+    from nerfail_amd import GaussNet as G, attack as A
+    s0, wi, ori_u8, victim = _toy_attack(seed=33)
+    label = torch.tensor(5, device=dev())
+    Ns = s0.numel() // 4
+    net = G.gauss_net(dev(), 0.02, victim, 'my_model', epsilon=None)
+    ref, ref_loss = A.nerfail_s_step(net, s0, s0, wi, torch.from_numpy(ori_u8).to(dev()), label, 2.0, 32.0, False)
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()
+    # (a) maps on disk in the reference's layout -> load_view_maps, images registered by id
+    mdir = str(tmp_path / 'index_and_weight')
+    os.makedirs(mdir)
+    for i in range(wi.shape[0]):
+        torch.save(wi[i].cpu(), os.path.join(mdir, '%d.pth' % i))
+    ids = G.load_view_maps(mdir, list(range(wi.shape[0])), Ns, images={i: ori_u8[i] for i in range(wi.shape[0])})
+    junk_wi = torch.zeros(tuple(wi.shape))                       # CPU tensors of the right shape and WRONG content
+    junk_ori = torch.zeros(ori_u8.shape, dtype=torch.uint8)
+    got, got_loss = A.nerfail_s_step(net, s0, s0, junk_wi, junk_ori, label, 2.0, 32.0, False, view_ids=ids)
+    assert torch.equal(got, ref) and float(got_loss) == float(ref_loss)
+    got2, _ = A.nerfail_s_step(net, s0, s0, None, None, label, 2.0, 32.0, False, view_ids=ids)      # nothing passed at all
+    assert torch.equal(got2, ref)
+    # shuffled composition (the DataLoader shuffles): the right views are found by id
+    perm = [3, 0, 4, 1, 2]
+    ref_p, _ = A.nerfail_s_step(net, s0, s0, wi[perm].contiguous(), torch.from_numpy(ori_u8[perm]).to(dev()), label, 2.0, 32.0, False)
+    got_p, _ = A.nerfail_s_step(net, s0, s0, junk_wi, junk_ori, label, 2.0, 32.0, False, view_ids=[ids[k] for k in perm])
+    assert torch.equal(got_p, ref_p)
+    # the full forward() of the module (reference signature) finds them too
+    x, xr, cla, o, ocla = net(s0, junk_wi, junk_ori, view_ids=ids)
+    x_r, xr_r, cla_r, o_r, _ = net(s0, wi, torch.from_numpy(ori_u8).to(dev()))
+    assert torch.equal(x, x_r) and torch.equal(xr, xr_r) and torch.equal(o, o_r) and torch.equal(cla, cla_r)
+    # (b) keep_views_resident: the first sight of an id uploads and keeps the view, later calls do not read the host tensors
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()
+    net.keep_views_resident = True
+    names = [('scene', 'test', i) for i in range(wi.shape[0])]
+    first, _ = A.nerfail_s_step(net, s0, s0, wi.cpu(), torch.from_numpy(ori_u8), label, 2.0, 32.0, False, view_ids=names)
+    later, _ = A.nerfail_s_step(net, s0, s0, junk_wi, junk_ori, label, 2.0, 32.0, False, view_ids=names)
+    assert torch.equal(first, ref) and torch.equal(later, ref)
+
+
+def test_view_ids_are_checked_and_stale_sidecars_are_rebuilt(tmp_path):
+    """ADVICE r2 (medium x2): (i) an id reused for a view of another resolution raises instead of reading out of bounds, an
+    id whose registered index belongs to another map is caught by the fingerprint on first use, register_view_index
+    refuses to overwrite silently; (ii) a <i>.idx.pth sidecar built from another version of <i>.pth is rebuilt."""
+    from nerfail_amd import GaussNet as G
+    s0, wi, ori_u8, _ = _toy_attack(seed=44)
+    ori = T(ori_u8.astype(np.float32))
+    Ns = s0.numel() // 4
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()
+    G.view_indices(wi[:2], Ns, [0, 1])
+    small = wi[:2, :, :7].contiguous()                             # "test view 0" at another resolution under the same bare id
+    with pytest.raises(ValueError):
+        G.view_indices(small, Ns, [0, 1])
+    # an index of ANOTHER map registered under an id: caught when the id is first used with a map at hand
+    other = G.ViewIndex(wi[3], Ns)
+    other.verified = False
+    G.register_view_index('v9', other, Ns)
+    with pytest.raises(ValueError):
+        G.view_indices(wi[2:3], Ns, ['v9'])
+    with pytest.raises(ValueError):
+        G.register_view_index('v9', G.ViewIndex(wi[4, :, :7].contiguous(), Ns), Ns)       # silent overwrite refused
+    # stale sidecar
+    mdir = str(tmp_path / 'maps')
+    os.makedirs(mdir)
+    torch.save(wi[0].cpu(), os.path.join(mdir, '0.pth'))
+    ids = G.load_view_indices(mdir, [0], Ns)
+    a = G._VIEW_CACHE[G._view_key(ids[0], Ns)]
+    torch.save(wi[1].cpu(), os.path.join(mdir, '0.pth'))           # the map is regenerated (another c / NeRF / resolution)
+    os.utime(os.path.join(mdir, '0.pth'), ns=(1, 1))
+    ids = G.load_view_indices(mdir, [0], Ns)
+    b = G._VIEW_CACHE[G._view_key(ids[0], Ns)]
+    assert tuple(a.fp) != tuple(b.fp) and tuple(b.fp) == tuple(G.fingerprints(wi[1:2])[0])
+    s = s0.clone().requires_grad_(True)
+    x, xr = G.gauss_gather(s, wi[1:2], ori[1:2], None, None, True, ids)
+    xr.sum().backward()
+    s2 = s0.clone().requires_grad_(True)
+    x2, xr2 = G.gauss_gather(s2, wi[1:2], ori[1:2], None, None, True)
+    xr2.sum().backward()
+    assert torch.equal(s.grad, s2.grad)

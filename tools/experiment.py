@@ -87,12 +87,12 @@ EXPERIMENTS = {
          '    if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(a.dz))[blockIdx.x] = wall_clock64() - nf_w0;\n')], []),
     # pricing of the training stores of the LDS-ring forward (mlp_lds.hip, TRAIN): default cache policy instead of nt / no
     # activation stores at all (backward then reads garbage: timing only) / no ReLU bit masks
-    'lds_train_nont': ('mlp_lds.hip', [('    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n',
-                                       '    asm volatile("global_store_dword %0, %1, %2" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n')], []),
-    'lds_train_nostore': ('mlp_lds.hip', [('    asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n',
-                                          '    asm volatile("" ::"v"(o), "v"(v), "s"(sbase) : "memory");\n')], []),
-    'lds_train_nomask': ('mlp_lds.hip', [('    asm volatile("global_store_short %0, %1, %2" ::"v"(o), "v"(bits), "s"(sentry) : "memory");\n',
-                                         '    asm volatile("" ::"v"(o), "v"(bits), "s"(sentry) : "memory");\n'),
+    'lds_train_nont': ('mlp_lds.hip', [('    asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(v), "s"(sbase), "i"(acc_reg_off(r) * 4) : "memory");\n',
+                                       '    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "i"(acc_reg_off(r) * 4) : "memory");\n')], []),
+    'lds_train_nostore': ('mlp_lds.hip', [('    asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(v), "s"(sbase), "i"(acc_reg_off(r) * 4) : "memory");\n',
+                                          '    asm volatile("" ::"v"(voff), "v"(v), "s"(sbase) : "memory");\n')], []),
+    'lds_train_nomask': ('mlp_lds.hip', [('    asm volatile("global_store_short %0, %1, %2 offset:%3" ::"v"(vlane16), "v"(bits), "s"(sentry), "i"(2 * t) : "memory");\n',
+                                         '    asm volatile("" ::"v"(vlane16), "v"(bits), "s"(sentry) : "memory");\n'),
                                         ('                    mk16 |= relu_bit(b[e]) << r;\n', '')], []),
     # pricing of the weight-gradient step loop (mlp_dw.hip): no LDS-DMA / no per-step barrier / no LDS operand reads / no row sums
     'dw_nodma': ('mlp_dw.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + voff[i]),\n                                         (lds_void_t*)(smem + rs * kDwStageFloats + (wave + 4 * i) * 256), 16, 0, 0);\n',
