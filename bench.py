@@ -402,66 +402,118 @@ def attack_bench(dev, iters=5):
         timed.blocks_ms = [round(v * 1e3, 4) for v in per_block]
         return float(np.median(per_block))
 
+    from nerfail_amd.GaussNet import resolve_views, hot_forward, hot_backward_rgb, register_view, _VIEW_MAPS, _VIEW_ORI, _VIEW_CACHE
+    from nerfail_amd.attack import igsm_step_rgb
+    alg_bytes = 8 * (102.4e6 + 81.9e6) + 122.9e6        # 1.60 GB / iteration
+    Ns = s_init.numel() // 4
+    ori_u8 = ori.to(torch.uint8)                        # what cv2.imread hands the reference's dataset (MyDataset.py:200)
+
+    def leg(dt):
+        return {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3, 'statistic': 'median of 5 blocks of %d iterations' % iters,
+                'ms_per_iter_each_block': timed.blocks_ms,
+                'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                             'note': 'algorithmic 1.60 GB per iteration as SURVEY 8(d) counts it (fp32 x and ori, all four '
+                                     'gradient channels); this form moves fewer bytes, see attack.gauss_kernels'}}
+
+    # (1) the path nerfail_s_step takes (round 3): forward without the x tensor, uint8 images, alpha + 3-bit mask handed to an
+    # rgb-gradient-only backward that writes [Ns,3], sign step on [Ns,3] (AS:357-392 reads grad[..., :3] only)
+    views = resolve_views(s_init, wi, ori_u8)
+    buf = torch.empty((3 * Ns + 1,), device=dev)
+
+    def one_iter_rgb(s):
+        _, x_rgba, aux = hot_forward(s, views, None, None, need_x=False, need_aux=True)
+        hot_backward_rgb(aux, G, views, buf)
+        return igsm_step_rgb(s, buf, s_init, 2.0, 32.0, False)
+    out['gauss_path_deterministic'] = leg(timed(one_iter_rgb, s_init.clone()))
+    out['gauss_path_deterministic']['form'] = 'rgb-gradient-only step path (attack.nerfail_s_step): K10 no-x/uint8-ori/aux, K11 rgb, K12 rgb'
+
+    # (2) the full autograd form (all four gradient channels, x materialised): what gauss_net.forward + loss.backward() run
     for det in (True, False):
         def one_iter(s, det=det):
             st = s.detach().requires_grad_(True)
             x, x_rgba = gauss_gather(st, wi, ori, None, None, det)
             x_rgba.backward(G)
             return igsm_step(st.detach(), st.grad, s_init, 2.0, 32.0, False)
-        dt = timed(one_iter, s_init.clone())
-        alg_bytes = 8 * (102.4e6 + 81.9e6) + 122.9e6        # 1.60 GB / iteration
-        out['gauss_path_' + ('deterministic' if det else 'atomics')] = {
-            'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3, 'statistic': 'median of 5 blocks of %d iterations' % iters,
-            'ms_per_iter_each_block': timed.blocks_ms,
-            'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
+        out['gauss_path_full_gradient_' + ('deterministic' if det else 'atomics')] = leg(timed(one_iter, s_init.clone()))
 
-    # the reference's DataLoader hands out a NEW map tensor every iteration (MyDataset.py:199-204).
-    # The per-view indices survive that; what it costs is recognising the views - a content fingerprint of the maps
-    # (one extra read of them) - unless the loop names its views (`view_ids`, the dataset index the loader returns).
-    fresh = [wi.clone() for _ in range(iters + 1)]
-    for tag, ids in (('fingerprinted', None), ('view_ids', list(range(B)))):
-        it_no = [0]
+    # (3) VERDICT r2 item 2 - the loop as the reference feeds it: a Dataset over the files on disk (index_and_weight/<i>.pth,
+    # <i>.png) behind a DataLoader(batch_size=8, num_workers=0) that is iterated every step (MyDataset.py:187-204, AS:222-231,
+    # AS:304-317). nerfail_amd.MyDataset.gauss_dataset reads a view ONCE and keeps it on the device by view id; (a) with its
+    # collate_views the batch is a list of those resident tensors (nothing copied), (b) with torch's default collate the eight
+    # resident maps are stacked into a fresh 328 MB device tensor per iteration, as the reference's loader does,
+    # (c) the reference's own behaviour - torch.load + imread of every view in every iteration - for comparison.
+    import shutil
+    import tempfile
+    from PIL import Image
+    from nerfail_amd.MyDataset import gauss_dataset
+    tmp = tempfile.mkdtemp(prefix='nf_bench_ds_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        maps, pngs = [], []
+        for b in range(B):
+            maps.append(os.path.join(tmp, '%d.pth' % b))
+            pngs.append(os.path.join(tmp, '%d.png' % b))
+            torch.save(wi[b].cpu(), maps[-1])
+            Image.fromarray(ori_u8[b].cpu().numpy()[..., [2, 1, 0, 3]], 'RGBA').save(pngs[-1])    # BGRA tensor -> RGBA file
+        names = [''] * B
+        for tag, resident, own_collate in (('resident_collate_views', True, True), ('resident_default_collate', True, False),
+                                           ('reload_every_iteration', False, False)):
+            _VIEW_MAPS.clear(); _VIEW_ORI.clear(); _VIEW_CACHE.clear()
+            ds = gauss_dataset(maps, pngs, names, names, dev, Ns=Ns if resident else None)
+            loader = torch.utils.data.DataLoader(ds, batch_size=B, shuffle=False, num_workers=0,
+                                                 collate_fn=ds.collate_views if own_collate else None)
 
-        def one_iter_fresh(s, ids=ids):
-            w_new = fresh[it_no[0] % len(fresh)].view(wi.shape)     # a new tensor OBJECT every iteration (no identity shortcut)
-            it_no[0] += 1
-            st = s.detach().requires_grad_(True)
-            x, x_rgba = gauss_gather(st, w_new, ori, None, None, True, ids)
-            x_rgba.backward(G)
-            return igsm_step(st.detach(), st.grad, s_init, 2.0, 32.0, False)
-        dt = timed(one_iter_fresh, s_init.clone())
-        out['gauss_path_fresh_map_tensor_every_iteration_' + tag] = {
-            'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
-            'roofline': {'bound': 'hbm', 'achieved': alg_bytes / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
-    del fresh
+            def one_iter_host(s):
+                for idx, ori_b, wi_b, _, _ in loader:             # one batch = all 8 views
+                    v = resolve_views(s, wi_b, ori_b)
+                    _, x_rgba, aux = hot_forward(s, v, None, None, need_x=False, need_aux=True)
+                    hot_backward_rgb(aux, G, v, buf)
+                    s = igsm_step_rgb(s, buf, s_init, 2.0, 32.0, False)
+                return s
+            dt = timed(one_iter_host, s_init.clone(), blocks=3)
+            out['gauss_path_host_dataloader_' + tag] = leg(dt)
+            out['gauss_path_host_dataloader_' + tag]['ratio_to_resident_path'] = dt * 1e3 / out['gauss_path_deterministic']['ms_per_iter']
+        out['gauss_path_host_dataloader_note'] = (
+            'DataLoader(num_workers=0) over index_and_weight/<i>.pth + <i>.png iterated every step. resident_collate_views: '
+            'nerfail_amd.MyDataset.gauss_dataset keeps each view on the device by id, the batch is a list of resident tensors; '
+            'resident_default_collate: same dataset, torch default_collate stacks 328 MB on the device per step; '
+            'reload_every_iteration: the reference behaviour (torch.load + imread per view and step, files in /dev/shm), '
+            'maps fingerprinted to find their cached inverted index')
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        _VIEW_MAPS.clear(); _VIEW_ORI.clear()
     out['gauss_kernels'] = gauss_kernel_rooflines(dev, wi, ori, s_init, G)
 
+    # end to end. The victim runs with MIOpen allowed to pick its solvers (torch.backends.cudnn.benchmark) and channels-last
+    # weights: without that MIOpen falls back to naive_conv_* kernels for some of these 800x800 layers (17 % of the profiled
+    # GPU time in round 2). Identical arithmetic; the untuned configuration is reported as the secondary line.
     torch.manual_seed(0)
     victim = victim_cnn(8).to(dev)
     victim.requires_grad_(False)                   # the attack differentiates w.r.t. the perturbation only
-    net = gauss_net(dev, 0.02, victim, 'my_model', epsilon=None)
     label = torch.tensor(4, device=dev)
-    dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
-    out['end_to_end_victim_cnn'] = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
-                                    'note': 'gauss_net.forward (2 classifier forwards) + CE + backward + sign step'}
-    # the same with MIOpen allowed to search for its solvers (torch.backends.cudnn.benchmark) and a channels-last victim:
-    # in the default configuration MIOpen falls back to naive_conv_* kernels for some of these 800x800 layers
-    if os.environ.get('NERFAIL_BENCH_TUNE_VICTIM', '1') == '1':
+    tuned = os.environ.get('NERFAIL_BENCH_TUNE_VICTIM', '1') == '1'
+    net_u = gauss_net(dev, 0.02, victim, 'my_model', epsilon=None)
+    dt = timed(lambda s: nerfail_s_step(net_u, s, s_init, wi, ori_u8, label, 2.0, 32.0, False)[0], s_init.clone())
+    untuned = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
+               'note': 'default MIOpen solver choice, NCHW victim: gauss_net forward (2 classifier forwards) + CE + backward + sign step'}
+    prev = torch.backends.cudnn.benchmark
+    if tuned:
         t_tune = time.time()
-        prev = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = True
         victim_t = victim_cnn(8).to(dev).to(memory_format=torch.channels_last).requires_grad_(False)
         victim_t.load_state_dict(victim.state_dict())
-        net_t = gauss_net(dev, 0.02, victim_t, 'my_model', epsilon=None)
-        dt = timed(lambda s: nerfail_s_step(net_t, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
-        torch.backends.cudnn.benchmark = prev
-        out['end_to_end_victim_cnn_tuned_miopen'] = {
+        net = gauss_net(dev, 0.02, victim_t, 'my_model', epsilon=None)
+        dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori_u8, label, 2.0, 32.0, False)[0], s_init.clone())
+        out['end_to_end_victim_cnn'] = {
             'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3, 'solver_search_seconds': time.time() - t_tune - dt * (iters + 1),
-            'note': 'torch.backends.cudnn.benchmark = True + channels_last victim (solver selection only; same arithmetic)'}
+            'note': 'torch.backends.cudnn.benchmark = True + channels_last victim (solver selection only; same arithmetic): '
+                    'gauss_net forward (2 classifier forwards) + CE + backward + sign step'}
+        out['end_to_end_victim_cnn_untuned_miopen'] = untuned
+    else:
+        net = net_u
+        out['end_to_end_victim_cnn'] = untuned
     net.cache_ori_cla = True                       # the unperturbed images' logits never change in the loop
-    dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori, label, 2.0, 32.0, False)[0], s_init.clone())
+    dt = timed(lambda s: nerfail_s_step(net, s, s_init, wi, ori_u8, label, 2.0, 32.0, False)[0], s_init.clone())
     out['end_to_end_victim_cnn_cached_original_logits'] = {
         'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
         'note': 'same, gauss_net.cache_ori_cla = True (1 classifier forward per step; identical results)'}
@@ -482,37 +534,65 @@ def attack_bench(dev, iters=5):
     out['deepfool_inner_loop'] = {'iters_per_sec': 1.0 / dt, 'ms_per_iter': dt * 1e3,
                                   'note': 'one 800x800 view, 8 class gradients per iteration: victim CNN fwd + 8 bwd (stock '
                                           'PyTorch) + one multi-RHS pass over the inverted index'}
+    torch.backends.cudnn.benchmark = prev
     out['batch_views'] = B
     out['unit'] = 'NeRFail-S iterations/s (batch of 8 views, 800x800, P=3)'
     return out
 
 
 def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
-    """K10 / K11 / K12 one by one through the C-ABI, HIP events on the launch stream, each against the HBM roof with its
-    own algorithmic bytes (102.4 MB and 81.9 MB per view, 122.9 MB per K12 step) and the PMC
-    traffic of its kernels (pmc_traffic: only when the stored counters were taken from these very sources)."""
+    """K10 / K11 / K12 of the step path (rgb-gradient form) one by one through the C-ABI, HIP events on the launch stream.
+    Bytes: `compulsory_bytes_per_call` = what THIS form has to move once (counted from the maps: background pixels read
+    their 32 bytes of weights only; the index stream of K11 is part of it), `survey_bytes_per_call` = SURVEY.md section 8d's
+    nominal figure (fp32 x and ori, four gradient channels) for reference. roofline.achieved / frac are taken from the PMC
+    traffic of the kernels when the stored counters belong to these sources (traffic / time: a rate that cannot exceed
+    the HBM peak), else from the compulsory bytes; K12's tables (3 x 30.7 MB) would sit in the 256 MB Infinity Cache across
+    back-to-back calls, so its calls rotate over 4 table sets (368 MB) and use distinct s / s_init buffers."""
     from nerfail_amd import _lib
-    from nerfail_amd.GaussNet import view_indices, view_table
+    from nerfail_amd.GaussNet import resolve_views, view_table
     lib = _lib.load()
     B, P, Ns = wi.shape[0], H * W, s_init.numel() // 4
     s = s_init.reshape(-1, 4).contiguous()
-    x, xr = torch.empty_like(ori), torch.empty_like(ori)
-    gs, s_new = torch.empty((Ns, 4), device=dev), torch.empty((Ns, 4), device=dev)
-    vis = view_indices(wi, Ns)                                # the per-view inverted indices (N2; built once, cached)
+    ori_u8 = ori.to(torch.uint8)
+    views = resolve_views(s_init, wi, ori_u8)
+    vtab = views.table()
+    xr = torch.empty((B, H, W, 4), device=dev)
+    aux_a, aux_m = torch.empty((B, H, W), device=dev), torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    vis = views.indices()                                     # the per-view inverted indices (N2; built once, cached)
     table, floats = view_table(vis)
     scratch = torch.empty((floats,), device=dev)
+    g3 = torch.empty((3 * Ns + 1,), device=dev)
     st = _lib.stream()
+    # compulsory bytes of this form, from the data
+    fg = float((wi[:, 0].abs().sum(-1) > 0).float().mean())                     # pixels with a non-zero weight
+    entries = float(sum(vi.n_entries for vi in vis))
+    rows = float(sum(vi.n_rows for vi in vis))
+    k10 = B * P * (32 + 32 * fg + 4 + 16 + 5) + Ns * 16                         # weights, indices (foreground), u8 ori, x_rgba, aux; table once
+    _lib.check(lib.nerfail_gauss_fwd_views(_lib.dev(s), Ns, vtab, B, P, 1, -1.0, None, _lib.dev(xr), _lib.dev(aux_a), _lib.dev(aux_m), None, st))
+    passing = float((aux_m != 0).float().mean())
+    k11 = (B * P * (1 + 20 * passing + 16) + B * P * 16                         # mask, alpha + G where it passes, g_pix write; g_pix read once
+           + entries * 8 + rows * 16 * 2 + B * Ns * 4 + Ns * 12)                # index stream, row sums w + r, pos per view, grad3
+    k12 = Ns * (16 + 12 + 16 + 16)
+    sets = [(torch.randn((Ns, 4), device=dev), torch.randn((3 * Ns + 1,), device=dev), torch.randn((Ns, 4), device=dev),
+             torch.empty((Ns, 4), device=dev)) for _ in range(4)]
+    rot = [0]
+
+    def k12_call():
+        a_, g_, i_, o_ = sets[rot[0] % 4]
+        rot[0] += 1
+        return lib.nerfail_igsm_step_rgb(_lib.dev(a_), _lib.dev(g_), _lib.dev(i_), Ns, 2.0, 32.0, 0, _lib.dev(o_), st)
     calls = {
-        'K10_gauss_fwd': (lambda: lib.nerfail_gauss_fwd(_lib.dev(s), Ns, _lib.dev(wi), _lib.dev(ori), B, P, -1.0, _lib.dev(x), _lib.dev(xr), None, st),
-                          B * 102.4e6, ('gauss_fwd_views_kernel',)),
-        'K11_gauss_bwd_views': (lambda: lib.nerfail_gauss_bwd_views(_lib.dev(ori), _lib.dev(x), None, _lib.dev(G), table, B, Ns, P, -1.0,
-                                                                   _lib.dev(scratch), _lib.dev(gs), st),
-                                B * 81.9e6, ('gauss_pixel_grad_kernel', 'gauss_seg_reduce_views_kernel', 'gauss_seg_combine_views_kernel', 'gauss_rows_sum_kernel')),
-        'K12_igsm_step': (lambda: lib.nerfail_igsm_step(_lib.dev(s), _lib.dev(gs), _lib.dev(s), Ns, 2.0, 32.0, 0, _lib.dev(s_new), st),
-                          122.9e6, ('igsm_step_kernel',)),
+        'K10_gauss_fwd': (lambda: lib.nerfail_gauss_fwd_views(_lib.dev(s), Ns, vtab, B, P, 1, -1.0, None, _lib.dev(xr), _lib.dev(aux_a),
+                                                              _lib.dev(aux_m), None, st),
+                          k10, B * 102.4e6, ('gauss_fwd_views_kernel',)),
+        'K11_gauss_bwd_views': (lambda: lib.nerfail_gauss_bwd_views_rgb(_lib.dev(aux_a), _lib.dev(aux_m), _lib.dev(G), table, B, Ns, P,
+                                                                       _lib.dev(scratch), _lib.dev(g3), st),
+                                k11, B * 81.9e6, ('gauss_pixel_grad_rgb_kernel', 'gauss_seg_reduce_views_kernel', 'gauss_seg_combine_views_kernel',
+                                                  'gauss_rows_sum3_kernel')),
+        'K12_igsm_step': (k12_call, k12, 122.9e6, ('igsm_step_rgb_kernel',)),
     }
     out = {}
-    for name, (fn, alg, kernels) in calls.items():
+    for name, (fn, comp, survey, kernels) in calls.items():
         for _ in range(2):
             _lib.check(fn())
         blocks = []
@@ -529,10 +609,17 @@ def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
         for k in kernels:                                     # PMC bytes per launch (every kernel launches once per call)
             t, src = pmc_traffic(k, 'max')                    # the 8-view batch is these kernels' largest launch
             traffic = None if (t is None or traffic is None) else traffic + t
-        out[name] = {'ms_per_call': ms, 'statistic': 'fastest of 3 blocks of %d calls' % n, 'kernels': list(kernels), 'algorithmic_bytes_per_call': alg,
-                     'roofline': {'bound': 'hbm', 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                  'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': src}}
+        moved = traffic if traffic is not None else comp
+        rate = moved / ms / 1e6
+        out[name] = {'ms_per_call': ms, 'statistic': 'fastest of 3 blocks of %d calls' % n, 'kernels': list(kernels),
+                     'compulsory_bytes_per_call': comp, 'survey_bytes_per_call': survey,
+                     'roofline': {'bound': 'hbm', 'achieved': rate, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': min(rate / HBM_PEAK_GBS, 1.0),
+                                  'bytes_used': 'pmc traffic' if traffic is not None else 'compulsory bytes of this form',
+                                  'traffic': traffic, 'traffic_source': src,
+                                  'survey_nominal_GBps': survey / ms / 1e6}}
     out['inverted_index_bytes_per_view'] = int(sum(vi.nbytes() for vi in vis) / len(vis))
+    out['foreground_pixel_fraction'] = fg
+    out['gradient_passing_pixel_fraction'] = passing
     return out
 
 
@@ -854,6 +941,13 @@ def main():
             metrics.append({'metric': 'attack iters/sec (end to end, one batch of 8 views split over ranks + C1 all-reduce)',
                             'unit': 'iterations/s', 'value': line['attack']['iters_per_sec'], 'n_gpus': world, 'roofline': None})
         line['metrics'] = metrics
+        # the same rooflines as top-level keys (the driver's parser keeps top-level objects)
+        if 'train' in line and line['train'].get('roofline'):
+            line['roofline_fwd_bwd'] = dict(line['train']['roofline'], kernel='whole training step (3 MLP kernel families)',
+                                            value_rays_per_sec=line['train']['train_rays_per_sec_fwd_bwd'])
+        if 'attack' in line and 'gauss_path_deterministic' in line['attack']:
+            line['roofline_attack'] = dict(line['attack']['gauss_path_deterministic']['roofline'], kernel='K10 + K11 + K12, 8 views',
+                                           value_iters_per_sec=line['attack']['gauss_path_deterministic']['iters_per_sec'])
         # the CPU baseline runs LAST: its 256 OpenBLAS worker threads keep spinning for a while after the last sgemm and
         # starve the Python launch thread of whatever GPU section follows (seen as a 7x slower training section)
         line['cpu_baseline'] = None

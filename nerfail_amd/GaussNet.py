@@ -326,6 +326,7 @@ class BatchViews:
     def __init__(self, wi, ori, ori_u8, view_ids, Ns, batch_wi=None, batch_ori=None):
         self.wi, self.ori, self.ori_u8, self.view_ids, self.Ns = wi, ori, ori_u8, view_ids, Ns
         self.batch_wi, self.batch_ori = batch_wi, batch_ori           # the contiguous batch tensors, when they came that way
+        self.ori_src = None          # identity of the image tensor the caller passed, when it lives on the device (logit cache key)
         self.B = len(wi)
         self.H, self.W = int(wi[0].shape[1]), int(wi[0].shape[2])
         self.P = self.H * self.W
@@ -356,6 +357,21 @@ def resolve_views(spatial_rgb, weight_and_index_list, ori_img, view_ids=None, ke
     dev = _cuda()
     Ns = int(spatial_rgb.numel() // 4)
     wi_in, ori_in = weight_and_index_list, ori_img
+    if isinstance(wi_in, (list, tuple)):
+        # a batch handed over as per-view tensors (MyDataset.collate_views): nothing is stacked, ids travel with the list
+        if view_ids is None and getattr(wi_in, 'view_ids', None) is not None:
+            view_ids = wi_in.view_ids
+        wl = [w if (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()) else _lib.f32c(w, dev) for w in wi_in]
+        ol = [(o.to(dev).contiguous() if o.dtype == torch.uint8 else _lib.f32c(o, dev)) for o in ori_in]
+        if len(wl) != len(ol) or (view_ids is not None and len(view_ids) != len(wl)):
+            raise ValueError('maps, images and view ids of a batch must have the same length')
+        H, W = wl[0].shape[1], wl[0].shape[2]
+        for w, o in zip(wl, ol):
+            if tuple(w.shape) != (2, H, W, 8) or tuple(o.shape) != (H, W, 4):
+                raise ValueError('a view must be a [2,H,W,8] map with a [H,W,4] image, got %s and %s' % (tuple(w.shape), tuple(o.shape)))
+        if len({o.dtype for o in ol}) > 1:
+            ol = [o.float() for o in ol]
+        return BatchViews(wl, ol, ol[0].dtype == torch.uint8, view_ids, Ns)
     B = len(view_ids) if view_ids is not None else wi_in.shape[0]
     keys = [_view_key(v, Ns) for v in view_ids] if view_ids is not None else [None] * B
     res_wi = [_VIEW_MAPS.get(k) if k is not None else None for k in keys]
@@ -399,7 +415,11 @@ def resolve_views(spatial_rgb, weight_and_index_list, ori_img, view_ids=None, ke
         # the kernels index ori / x as [B*H*W] pixels and the table as float4[Ns]: mismatched shapes would read out of bounds
         if tuple(w.shape) != (2, H, W, 8) or tuple(o.shape) != (H, W, 4):
             raise ValueError('ori_img must be [B,H,W,4] with the B, H, W of weight_and_index_list, got %s vs %s' % (tuple(o.shape), tuple(w.shape)))
-    return BatchViews(res_wi, res_ori, res_ori[0].dtype == torch.uint8, view_ids, Ns, batch_wi, batch_ori)
+    bv = BatchViews(res_wi, res_ori, res_ori[0].dtype == torch.uint8, view_ids, Ns, batch_wi, batch_ori)
+    if isinstance(ori_in, torch.Tensor) and ori_in.is_cuda:
+        bv.ori_src = ('tensor', ori_in.data_ptr(), ori_in._version, tuple(ori_in.shape), str(ori_in.dtype))
+        bv._ori_keep = ori_in        # the address cannot be recycled while the key may be looked up
+    return bv
 
 
 def hot_forward(spatial_rgb, views, epsilon=None, eps_minmax=None, need_x=True, need_aux=False):
@@ -600,7 +620,8 @@ class gauss_net(nn.Module):
                     self._ori_cla_cache.clear()
                 ori_cla, o = ori_logits(False)
                 self._ori_cla_cache[ori_key] = ori_cla
-                self._ori_cla_keep = getattr(self, '_ori_cla_keep', [])[-63:] + [o]   # keeps data_ptr from being recycled
+                keep = getattr(self, '_ori_keep_src', None)
+                self._ori_cla_keep = getattr(self, '_ori_cla_keep', [])[-63:] + [o if keep is None else keep]   # keeps data_ptr from being recycled
         else:
             ori_cla, _ = ori_logits(True)
         return cla, ori_cla
@@ -617,8 +638,11 @@ class gauss_net(nn.Module):
         views = resolve_views(s, weight_and_index_list, ori_img, view_ids, self.keep_views_resident)
         _, x_rgba, aux = hot_forward(s, views, self.epsilon, self._mm() if self.update_epsilon_3d else None, need_x=False, need_aux=True)
         x_rgba.requires_grad_(True)
-        key = ('ids', tuple(_view_key(v, views.Ns) for v in view_ids)) if view_ids is not None else None
+        vids = views.view_ids
+        key = ('ids', tuple(_view_key(v, views.Ns) for v in vids)) if vids is not None else views.ori_src
+        self._ori_keep_src = getattr(views, '_ori_keep', None)
         cla, ori_cla = self.cold_tail(x_rgba, views.ori_float, ori_key=key)
+        self._ori_keep_src = None
         return x_rgba, cla, ori_cla, views, aux
 
     # ---- all class-logit gradients of one forward in ONE pass over the inverted index (DeepFool)

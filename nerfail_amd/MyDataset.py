@@ -1,0 +1,99 @@
+"""Mirror of the attack datasets of MyDataset.py (reference = MD): `gauss_dataset` (MD:187-204) and
+`gauss_dataset_rand_select` (MD:207-232, seed 1003) - same constructor arguments, same 5-tuple per item
+(index, ori_img uint8 BGRA [H,W,4], img_index_and_dist float32 [2,H,W,8], save name, mask save name).
+
+What differs is WHERE the tensors come from. The reference reads the PNG and `torch.load`s the 41 MB map from disk for
+every item of every iteration (MD:199-204) and the DataLoader stacks eight of them into a fresh batch tensor. A view's map
+and image never change, so here an item is loaded ONCE and then lives on the device under its view id (GaussNet.
+register_view; 288 GB of HBM hold a whole scene); later __getitem__ calls return those resident tensors, and
+`collate_views` hands the batch to gauss_net.forward / nerfail_s_step as a list of per-view tensors plus their ids instead of
+stacking 328 MB per iteration. With the default collate function the batch is a stacked DEVICE tensor, as in the reference.
+Host-side file I/O only; PNG decoding through cv2 when present (as the reference), else PIL."""
+import os
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import GaussNet as _G
+from .run_nerf_helpers import _cuda
+
+
+def _imread_unchanged(path):
+    """cv2.imread(path, cv2.IMREAD_UNCHANGED): uint8 [H,W,4] in BGRA order."""
+    try:
+        import cv2
+        return cv2.imread(path, cv2.IMREAD_UNCHANGED)
+    except ImportError:
+        from PIL import Image
+        a = np.asarray(Image.open(path).convert('RGBA'))
+        return np.ascontiguousarray(a[..., [2, 1, 0, 3]])
+
+
+class ViewList(list):
+    """A batch as per-view tensors (no stacking) + the ids under which the views are resident."""
+
+    def __init__(self, items, view_ids):
+        super().__init__(items)
+        self.view_ids = list(view_ids)
+
+    @property
+    def shape(self):
+        return (len(self),) + tuple(self[0].shape)
+
+
+class gauss_dataset(Dataset):
+    """MD:187-204. `Ns` (rows of the perturbation table, P*H*W) switches residency on: items are then kept on the device by
+    view id = absolute path of the map file, together with their inverted index."""
+
+    def __init__(self, all_index_and_dist_name_list, all_img_name_list, all_img_save_to_name_list, all_img_mask_save_to_name_list,
+                 device, Ns=None):
+        self.length = len(all_img_name_list)
+        self.all_index_and_dist_name_list = all_index_and_dist_name_list
+        self.all_img_name_list = all_img_name_list
+        self.all_img_save_to_name_list = all_img_save_to_name_list
+        self.all_img_mask_save_to_name_list = all_img_mask_save_to_name_list
+        self.device = device
+        self.Ns = Ns
+
+    def __len__(self):
+        return self.length
+
+    def view_id(self, index):
+        return os.path.abspath(self.all_index_and_dist_name_list[index])
+
+    def __getitem__(self, index):
+        dev = _cuda()
+        key = _G._view_key(self.view_id(index), self.Ns) if self.Ns is not None else None
+        wi = _G._VIEW_MAPS.get(key) if key is not None else None
+        ori = _G._VIEW_ORI.get(key) if key is not None else None
+        if ori is None:
+            ori = torch.tensor(_imread_unchanged(self.all_img_name_list[index])).to(dev)
+        if wi is None:
+            wi = torch.load(self.all_index_and_dist_name_list[index], map_location=dev)
+        if key is not None and (key not in _G._VIEW_MAPS or key not in _G._VIEW_ORI):
+            _G.register_view(self.view_id(index), self.Ns, weight_and_index=wi, ori_img=ori)
+            wi, ori = _G._VIEW_MAPS[key], _G._VIEW_ORI[key]
+        return index, ori, wi, self.all_img_save_to_name_list[index], self.all_img_mask_save_to_name_list[index]
+
+    def collate_views(self, batch):
+        """collate_fn for the DataLoader: (indices, ori_img ViewList, img_index_and_dist ViewList, save names, mask names) -
+        nothing is stacked; the ViewLists carry the view ids gauss_net.forward / nerfail_s_step look the views up by."""
+        idx = [b[0] for b in batch]
+        ids = [self.view_id(i) for i in idx] if self.Ns is not None else None
+        return (torch.tensor(idx), ViewList([b[1] for b in batch], ids or idx), ViewList([b[2] for b in batch], ids or idx),
+                [b[3] for b in batch], [b[4] for b in batch])
+
+
+class gauss_dataset_rand_select(gauss_dataset):
+    """MD:207-232: a fixed random subset (seed 1003) of the views."""
+
+    def __init__(self, all_index_and_dist_name_list, all_img_name_list, all_img_save_to_name_list, all_img_mask_save_to_name_list,
+                 device, select_rate=0.2, Ns=None):
+        random.seed(1003)
+        ori_length = len(all_img_name_list)
+        n = int(ori_length * select_rate)
+        sel = random.sample(range(ori_length), n)
+        super().__init__([all_index_and_dist_name_list[i] for i in sel], [all_img_name_list[i] for i in sel],
+                         [all_img_save_to_name_list[i] for i in sel], [all_img_mask_save_to_name_list[i] for i in sel], device, Ns)

@@ -84,6 +84,8 @@ def sharded_perturbation_grad_rgb(net, spatial, weight_and_index, ori_img, label
     """perturbation_grad_rgb of this rank's share of the batch's views, then ONE all-reduce of the 3 Ns + 1 floats (C1: the
     gradient and, in its tail, the loss). Identical on every rank."""
     world, rank = sharding.world_and_rank(group)
+    if view_ids is None and getattr(weight_and_index, 'view_ids', None) is not None:
+        view_ids = weight_and_index.view_ids                # a MyDataset.collate_views batch: ids travel with the list
     B = len(view_ids) if view_ids is not None else weight_and_index.shape[0]
     lo, hi = sharding.shard_range(B, rank, world)
     Ns = spatial.numel() // 4

@@ -476,3 +476,66 @@ def test_view_ids_are_checked_and_stale_sidecars_are_rebuilt(tmp_path):
     x2, xr2 = G.gauss_gather(s2, wi[1:2], ori[1:2], None, None, True)
     xr2.sum().backward()
     assert torch.equal(s.grad, s2.grad)
+
+
+def test_dataset_mirror_feeds_the_step_from_resident_views(tmp_path):
+    """nerfail_amd.MyDataset.gauss_dataset (mirror of MyDataset.py:187-204) behind a DataLoader(num_workers=0), as AS:222-231
+    / AS:304-317 drive the step: with its collate_views the batch is a list of device-resident views (read once), with the
+    default collate a stacked device tensor as in the reference - both give the bits of the plain tensor path."""
+    from PIL import Image
+    from nerfail_amd import GaussNet as G, attack as A
+    from nerfail_amd.MyDataset import gauss_dataset
+    s0, wi, ori_u8, victim = _toy_attack(seed=55, B=4)
+    label = torch.tensor(2, device=dev())
+    Ns = s0.numel() // 4
+    net = G.gauss_net(dev(), 0.02, victim, 'my_model', epsilon=None)
+    ref, ref_loss = A.nerfail_s_step(net, s0, s0, wi, torch.from_numpy(ori_u8).to(dev()), label, 2.0, 32.0, False)
+    maps, pngs = [], []
+    for b in range(4):
+        maps.append(str(tmp_path / ('%d.pth' % b)))
+        pngs.append(str(tmp_path / ('%d.png' % b)))
+        torch.save(wi[b].cpu(), maps[-1])
+        Image.fromarray(ori_u8[b][..., [2, 1, 0, 3]], 'RGBA').save(pngs[-1])          # BGRA array -> RGBA file (cv2 reads BGRA back)
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()
+    for own in (True, False):
+        ds = gauss_dataset(maps, pngs, [''] * 4, [''] * 4, dev(), Ns=Ns)
+        loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0, collate_fn=ds.collate_views if own else None)
+        for epoch in range(2):                                   # second epoch: everything comes from the device
+            for idx, ori_b, wi_b, _, _ in loader:
+                got, got_loss = A.nerfail_s_step(net, s0, s0, wi_b, ori_b, label, 2.0, 32.0, False)
+                assert torch.equal(got, ref) and float(got_loss) == float(ref_loss), (own, epoch)
+    assert len(G._VIEW_MAPS) == 4 and len(G._VIEW_ORI) == 4
+
+
+def test_attack_step_reuses_cached_original_logits():
+    """cache_ori_cla on the step's fast path: the original images' logits are computed once per image tensor (device tensor
+    identity) or per set of view ids, not in every step (GN:157 recomputes them every forward)."""
+    from nerfail_amd import GaussNet as G, attack as A
+    s0, wi, ori_u8, victim = _toy_attack(seed=66, B=3)
+    calls = []
+
+    class Counting(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            calls.append(x.shape[0])
+            return self.m(x)
+    net = G.gauss_net(dev(), 0.02, Counting(victim), 'my_model', epsilon=None)
+    label = torch.tensor(1, device=dev())
+    ori_d = torch.from_numpy(ori_u8).to(dev())
+    ref, _ = A.nerfail_s_step(net, s0, s0, wi, ori_d, label)
+    assert len(calls) == 2                                       # perturbed + original
+    net.cache_ori_cla = True
+    calls.clear()
+    a, _ = A.nerfail_s_step(net, s0, s0, wi, ori_d, label)
+    b, _ = A.nerfail_s_step(net, s0, s0, wi, ori_d, label)
+    assert len(calls) == 3 and torch.equal(a, ref) and torch.equal(b, ref)      # 2 + 1: the second step reuses the logits
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()
+    net.keep_views_resident = True
+    calls.clear()
+    ids = [('s', i) for i in range(3)]
+    c, _ = A.nerfail_s_step(net, s0, s0, wi.cpu(), torch.from_numpy(ori_u8), label, view_ids=ids)
+    d, _ = A.nerfail_s_step(net, s0, s0, None, None, label, view_ids=ids)
+    assert len(calls) == 3 and torch.equal(c, ref) and torch.equal(d, ref)
