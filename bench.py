@@ -63,6 +63,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f
 HBM_PEAK_GBS = 8000.0
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; the contract is ONE JSON line there. While the
+    process group is set up (and the first collective creates the communicator) fd 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def kernel_source_hash():
     """sha256 (16 hex digits) over nerfail_amd/csrc: ties a stored PMC measurement to the kernels it was taken from."""
     import hashlib
@@ -676,7 +691,7 @@ def cfg3_bench(dev, iters=20, n_views=16, batch=8):
                     'the analytic sphere pts_max; original-image logits cached (identical results)'}
 
 
-def multi_gpu_legs(dev, world, rank, steps, nets, K):
+def multi_gpu_legs(dev, world, rank, steps, nets, K, legs=('render', 'attack')):
     """N > 1 only. (a) strong-scaling render: ONE view per step, its 640 000 rays cut into contiguous per-rank ranges
     (sharding.render_shard; no collective). (b) NeRFail-S attack step, cfg5 shape: the 8 views of ONE batch split over
     ranks, one all-reduce (C1, RCCL over xGMI) of the 30.72 MB perturbation gradient, identical sign step everywhere."""
@@ -709,10 +724,14 @@ def multi_gpu_legs(dev, world, rank, steps, nets, K):
         c2w = torch.from_numpy(synth.pose_spherical(float(thetas[i % len(thetas)]), -30., 4.)[:3, :4])
         with torch.no_grad():
             return sharding.render_shard(H, W, K, c2w, 2., 6., rank, world, chunk=H * W, **kw)
-    dt = timed(strong, steps)
-    out = {'render_strong': {'rays_per_sec': steps * H * W / dt, 'ms_per_view': dt / steps * 1e3, 'scaling': 'strong',
-                             'rays_per_rank': [hi - lo for lo, hi in sharding.shard_ranges(H * W, world)],
-                             'note': 'one 800x800 view per step, contiguous ray ranges per rank, no collective'}}
+    out = {}
+    if 'render' in legs:
+        dt = timed(strong, steps)
+        out['render_strong'] = {'rays_per_sec': steps * H * W / dt, 'ms_per_view': dt / steps * 1e3, 'scaling': 'strong',
+                                'rays_per_rank': [hi - lo for lo, hi in sharding.shard_ranges(H * W, world)],
+                                'note': 'one 800x800 view per step, contiguous ray ranges per rank, no collective'}
+    if 'attack' not in legs:
+        return out
 
     B = 8
     wi, ori, s_init = _attack_inputs(dev, B, seed=60)
@@ -747,8 +766,10 @@ def multi_gpu_legs(dev, world, rank, steps, nets, K):
                      'allreduce_bus_GBps': (2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9) if ar else None,
                      'xgmi_per_link_peak_GBps': 153.0, 'ranks_seen': seen,
                      'perturbation_identical_on_all_ranks': bool(float(lo_[0]) == float(hi_[0])),
-                     'note': 'NeRFail-S step (AS:304-392) end to end with the stand-in 800x800 victim CNN; bus GB/s = '
-                             '2(N-1)/N x bytes / time (ring-equivalent), to compare with one xGMI link'}
+                     'expected_allreduce_ms_8_gpus': '0.05 (direct reduce-scatter + all-gather over 7 links) .. 0.35 (ring, one link), SURVEY section 5',
+                     'note': 'NeRFail-S step (AS:304-392) end to end with the stand-in 800x800 victim CNN; ONE collective per step: '
+                             'the [Ns,3] gradient with the loss in its tail (23.04 MB + 4 B); bus GB/s = 2(N-1)/N x bytes / time '
+                             '(ring-equivalent), to compare with one xGMI link'}
     return out
 
 
@@ -775,10 +796,13 @@ def main():
     dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        with _StdoutToStderr():
+            if args.dist_backend == 'nccl':
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+                dist.all_reduce(torch.zeros(1, device=dev))          # creates the communicator now (banner -> stderr)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
 
     from nerfail_amd import nerf_to_coord as NC, run_nerf as RN
@@ -919,6 +943,24 @@ def main():
                     line['render_f16x3']['speedup_vs_f32_kernel_this_run'] = line['render_f16x3']['rays_per_sec'] / line['value']
         if legs is not None:
             line.update(legs)
+        if world == 1 and os.environ.get('NERFAIL_BENCH_DRYRUN_NCCL', '0') == '1':
+            # RCCL dry run on one GPU: a 1-rank nccl group bound to the device, the attack leg's gradient all-reduce issued
+            # through it (sum over one rank = identity) - communicator, stream semantics and HIP-event timing executed once
+            try:
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                os.environ.setdefault('MASTER_PORT', '29517')
+                with _StdoutToStderr():
+                    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+                    dist.all_reduce(torch.zeros(1, device=dev))
+                    torch.cuda.synchronize()
+                os.environ['NERFAIL_FORCE_COLLECTIVE'] = '1'
+                line['attack_nccl_dryrun'] = multi_gpu_legs(dev, 1, 0, args.steps, (coarse, fine), K, legs=('attack',))['attack']
+            except Exception as e:
+                line['attack_nccl_dryrun_error'] = '%s: %s' % (type(e).__name__, str(e)[:300])
+            finally:
+                os.environ['NERFAIL_FORCE_COLLECTIVE'] = '0'
+                if dist.is_initialized():
+                    dist.destroy_process_group()
         # BASELINE.json's metric string names three numbers: rays/s forward (value above), rays/s fwd+bwd, attack
         # iterations/s. Each with its own roofline object, in one list the driver's parser keeps.
         metrics = [{'metric': 'rays/sec (render, forward)', 'value': line['value'], 'unit': 'rays/s', 'n_gpus': world,

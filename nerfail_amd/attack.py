@@ -95,7 +95,7 @@ def sharded_perturbation_grad_rgb(net, spatial, weight_and_index, ori_img, label
                                        view_ids=None if view_ids is None else list(view_ids)[lo:hi])
     else:                                   # more ranks than views: this rank only takes part in the sum
         buf = torch.zeros((3 * Ns + 1,), dtype=torch.float32, device=_cuda())
-    if world > 1:
+    if world > 1 or sharding.force_collectives():
         if timing is not None and buf.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

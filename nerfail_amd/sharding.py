@@ -31,18 +31,27 @@ def world_and_rank(group=None):
 _STAGE = {}
 
 
+def force_collectives():
+    """NERFAIL_FORCE_COLLECTIVE=1: issue the all-reduce even in a 1-rank group (a dry run of the RCCL path on a one-GPU box:
+    communicator creation, stream semantics and event timing are exercised; the sum over one rank is the identity)."""
+    import os
+    return os.environ.get('NERFAIL_FORCE_COLLECTIVE', '0') == '1'
+
+
 def all_reduce_sum_(t, group=None):
-    """In-place sum over ranks. RCCL all-reduce for HIP tensors under the nccl backend (the GPU-box path, xGMI);
-    under any other backend (gloo: the CPU tests and the one-GPU rehearsal, where RCCL refuses two ranks on one
-    device) a HIP tensor is staged through a pinned host buffer, reduced there and copied back."""
-    world, _ = world_and_rank(group)
-    if world <= 1:
+    """In-place sum over ranks. RCCL all-reduce for HIP tensors whenever the group has a device-capable backend ('nccl', a
+    'cpu:gloo,cuda:nccl' pair, or the default-initialised group that maps to it): the GPU-box path, xGMI. Only under a pure
+    'gloo' group (the CPU tests and the one-GPU rehearsal, where RCCL refuses two ranks on one device) a HIP tensor is
+    staged through a pinned host buffer (kept per size), reduced there and copied back."""
+    if not (dist.is_available() and dist.is_initialized()):
         return t
-    if t.is_cuda and dist.get_backend(group) != 'nccl':
+    world = dist.get_world_size(group)
+    if world <= 1 and not force_collectives():
+        return t
+    if t.is_cuda and str(dist.get_backend(group)) == 'gloo':
         key = (t.numel(), t.dtype)
         h = _STAGE.get(key)
         if h is None:
-            _STAGE.clear()
             h = _STAGE[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
         h.copy_(t.reshape(-1), non_blocking=False)
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)

@@ -98,3 +98,18 @@ def test_render_shards_concatenate_bitwise(runs):
         assert np.array_equal(cat.view(np.uint32), full.view(np.uint32)), k     # bitwise, NaNs of disp included
         assert np.array_equal(one['render_' + k].view(np.uint32), full.view(np.uint32)), k
     assert np.isfinite(one['full_rgb_map']).all() and (one['full_acc_map'] > 0).any()
+
+
+def test_rccl_path_one_rank_dry_run(rank_launcher, tmp_path):
+    """the nccl (= RCCL) branch executed once on the one-GPU box - a 1-rank 'nccl' process group bound
+    to the device, the product's 3 Ns + 1 float gradient buffer all-reduced through it on the current stream, HIP events
+    around the collective. The sum over one rank is the identity: same bits as without a process group."""
+    rep = rank_launcher(os.path.join(ROOT, 'tests', 'mgpu', 'nccl1.py'), 1, [str(tmp_path)], timeout=420)
+    assert rep['rc'] == [0], '\n'.join(rep['logs'])
+    r = np.load(tmp_path / 'nccl1.npz')
+    assert str(r['backend']) == 'nccl'
+    assert np.array_equal(r['got'], r['ref']) and np.array_equal(r['s_got'], r['s_ref'])
+    assert len(r['allreduce_ms']) == 2 and (r['allreduce_ms'] > 0).all()
+    assert (r['allreduce_bytes'] == r['got'].size * 4).all()                  # ONE collective carries gradient + loss
+    assert r['minmax'][0] == r['minmax'][1] == r['minmax'][2]
+    print('RCCL 1-rank all-reduce of %d bytes: %s ms' % (int(r['allreduce_bytes'][0]), np.round(r['allreduce_ms'], 3)))
