@@ -157,6 +157,13 @@ size_t nerfail_mlp_train_dz_floats(int D, int W, int64_t M);
 /* nerfail_mlp_fwd that additionally writes every layer's activation to `acts` (register-fragment layout). */
 int nerfail_mlp_fwd_train(const float* packed, int D, int W, int skip, const float* pts, const float* viewdirs,
                           int64_t M, int samples_per_ray, float* raw, float* acts, void* stream);
+/* The north-star form of nerfail_mlp_fwd / nerfail_mlp_fwd_train: the sample points are formed INSIDE the kernel from the
+ * packed rays [n_rays,11] and the depths z_vals [n_rays, samples_per_ray] - pts = o + d * z with the reference's rounding
+ * (RN:381, :399) - so the [M,3] point tensor is never written or read (nerfail_sample_coarse / nerfail_sample_fine accept
+ * pts = NULL, nerfail_composite forms pts_max from the ray when pts is NULL). acts: NULL, or the training forward's
+ * activation buffer (nerfail_mlp_train_acts_floats). Same bits as the pts form. */
+int nerfail_mlp_fwd_rays(const float* packed, int D, int W, int skip, const float* rays, const float* z_vals,
+                         int64_t n_rays, int samples_per_ray, float* raw, float* acts, void* stream);
 /* Transposed weight image for the backward-data pass (re-pack after every optimizer step). */
 size_t nerfail_mlp_packed_T_floats(int D, int W, int skip);
 int nerfail_mlp_pack_T(const nerfail_mlp_params* params_host, float* packedT, void* stream);
@@ -193,7 +200,8 @@ int nerfail_mlp_bwd_weights(int D, int W, int skip, const float* acts, const flo
 /* raw2outputs, RN:262-305, one wavefront per ray with a wave-level exclusive product scan.
  * raw[R,N,4], z_vals[R,N], rays (packed [R,11]; d is read from it), noise[R,N] already scaled by
  * raw_noise_std or NULL. Outputs rgb_map[R,3], disp_map[R], acc_map[R], weights[R,N], depth_map[R];
- * if pts[R,N,3] and pts_max[R,3] are non-NULL also NC:418-423 (first argmax of weights -> point). */
+ * if pts_max[R,3] is non-NULL also NC:418-423 (first argmax of weights -> point): gathered from pts[R,N,3], or - pts
+ * NULL - formed from the ray and its depth (o + d * z, the same bits). */
 int nerfail_composite(const float* raw, const float* z_vals, const float* rays, const float* noise,
                       int64_t n_rays, int n_samples, int white_bkgd,
                       float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
@@ -223,6 +231,12 @@ size_t nerfail_knn8_grid_workspace_bytes(int64_t n_points);
 int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* points, int64_t n_points,
                       float* dist, float* idx_f32, int32_t* idx_i32, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* The two halves of nerfail_knn8_grid: the grid of a point set is built ONCE into `workspace` (CI:57-61 stacks the base
+ * views of a scene once) and searched for every view of the scene (CI:110-163: 400 of them) - same results, the build's
+ * ~1 ms per view saved. The workspace must not be modified between build and search. */
+int nerfail_knn8_grid_build(const float* points, int64_t n_points, void* workspace, size_t workspace_bytes, void* stream);
+int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_points, float* dist, float* idx_f32,
+                             int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ gauss path (K9-K12) --- */
 

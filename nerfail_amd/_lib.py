@@ -50,6 +50,7 @@ SIGNATURES = {
     'nerfail_mlp_packed_floats': (ctypes.c_size_t, [c_i, c_i, c_i]),
     'nerfail_mlp_pack': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),
     'nerfail_mlp_fwd': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
+    'nerfail_mlp_fwd_rays': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
     'nerfail_mlp_fwd_select': (c_i, [c_i]),
     'nerfail_mlp_fwd_embedded': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p]),
     'nerfail_mlp_f16_image_bytes': (ctypes.c_size_t, [c_i, c_i, c_i]),
@@ -75,6 +76,8 @@ SIGNATURES = {
     'nerfail_knn8': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
     'nerfail_knn8_grid_workspace_bytes': (ctypes.c_size_t, [c_i64]),
     'nerfail_knn8_grid': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    'nerfail_knn8_grid_build': (c_i, [c_p, c_i64, c_p, ctypes.c_size_t, c_p]),
+    'nerfail_knn8_grid_search': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),

@@ -121,6 +121,20 @@ def mlp_fwd_train(net, pts, viewdirs, acts=None):
     return raw, acts
 
 
+def mlp_fwd_train_rays(net, rays, z_vals, acts=None):
+    """mlp_fwd_train with the sample points formed inside the kernel (nerfail_mlp_fwd_rays): rays [R,11], z_vals [R,N]."""
+    R, N = z_vals.shape
+    if acts is None:
+        acts = torch.empty((acts_floats(net, R * N),), dtype=torch.float32, device=z_vals.device)
+    elif acts.numel() != acts_floats(net, R * N):
+        raise ValueError('acts buffer has %d floats, the pass needs %d' % (acts.numel(), acts_floats(net, R * N)))
+    packed_both(net)
+    raw = torch.empty((R, N, 4), dtype=torch.float32, device=z_vals.device)
+    _lib.check(_lib.load().nerfail_mlp_fwd_rays(_lib.dev(net.packed()), net.D, net.W, net._skip(), _lib.dev(rays), _lib.dev(z_vals), R, N,
+                                                _lib.dev(raw), _lib.dev(acts), _lib.stream()))
+    return raw, acts
+
+
 def _same_arch(a, b):
     return (a.D, a.W, a._skip(), getattr(a, 'precision', 'f32')) == (b.D, b.W, b._skip(), getattr(b, 'precision', 'f32'))
 

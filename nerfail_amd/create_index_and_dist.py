@@ -35,18 +35,38 @@ def knn8(queries, points, want_int=False, method='auto'):
     if method == 'auto':
         method = 'grid' if p.shape[0] >= 4096 else 'brute'
     if method == 'grid':
-        nbytes = lib.nerfail_knn8_grid_workspace_bytes(p.shape[0])
-        if nbytes == 0:
-            raise _lib.NerfailError('nerfail_knn8_grid: unsupported point count %d (need 8 <= M < 2^24)' % p.shape[0])
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        _lib.check(lib.nerfail_knn8_grid(_lib.dev(q2, 'queries'), q2.shape[0], _lib.dev(p, 'points'), p.shape[0],
-                                         _lib.dev(dist), idx_f, idx_i, _lib.dev(ws), nbytes, _lib.stream()))
+        ws, nbytes = _grid_for(p)
+        _lib.check(lib.nerfail_knn8_grid_search(_lib.dev(q2, 'queries'), q2.shape[0], p.shape[0], _lib.dev(dist), idx_f, idx_i,
+                                                _lib.dev(ws), nbytes, _lib.stream()))
     elif method == 'brute':
         _lib.check(lib.nerfail_knn8(_lib.dev(q2, 'queries'), q2.shape[0], _lib.dev(p, 'points'), p.shape[0],
                                     _lib.dev(dist), idx_f, idx_i, _lib.stream()))
     else:
         raise ValueError('method must be auto, grid or brute')
     return dist.reshape(tuple(lead) + (8,)), idx.reshape(tuple(lead) + (8,))
+
+
+_GRID = {}          # the built grid of the last few point sets: (address, version, n) -> (workspace, bytes, the set itself)
+
+
+def _grid_for(p):
+    """The search grid of the point set `p` [M,3], built on first use and kept (a scene's set is fixed while its 400 views are
+    processed, CI:57-61 / CI:110-163): keyed on the tensor's identity - address, version counter and size - with the
+    tensor kept alive, so a recycled address cannot alias."""
+    lib = _lib.load()
+    key = (p.data_ptr(), p._version, p.shape[0])
+    hit = _GRID.get(key)
+    if hit is not None:         # (hit[2] shares p's storage and keeps it alive: the address cannot have been recycled)
+        return hit[0], hit[1]
+    nbytes = lib.nerfail_knn8_grid_workspace_bytes(p.shape[0])
+    if nbytes == 0:
+        raise _lib.NerfailError('nerfail_knn8_grid: unsupported point count %d (need 8 <= M < 2^24)' % p.shape[0])
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=p.device)
+    _lib.check(lib.nerfail_knn8_grid_build(_lib.dev(p, 'points'), p.shape[0], _lib.dev(ws), nbytes, _lib.stream()))
+    while len(_GRID) >= 4:
+        _GRID.pop(next(iter(_GRID)))
+    _GRID[key] = (ws, nbytes, p)
+    return ws, nbytes
 
 
 def index_and_dist(view_pts, point_set, method='auto'):

@@ -87,7 +87,13 @@ __global__ __launch_bounds__(256) void composite_kernel(
             if (ow > best_w || (ow == best_w && oi < best_i)) { best_w = ow; best_i = oi; }
         }
         if (best_i >= N) best_i = 0;   // all-NaN weights: never index outside the ray
-        if (lane < 3) pts_max[3 * ray + lane] = pts[3 * (base + best_i) + lane];
+        if (lane < 3) {
+            // the sample point of the largest weight: gathered from pts, or formed from the ray (o + d z, RN:399 rounding)
+            // when the pipeline no longer materialises the points (round 3)
+            pts_max[3 * ray + lane] = pts != nullptr ? pts[3 * (base + best_i) + lane]
+                                                     : mul_add_rn(rays[NERFAIL_RAY_FLOATS * ray + 3 + lane], z_vals[base + best_i],
+                                                                  rays[NERFAIL_RAY_FLOATS * ray + lane]);
+        }
     }
 
     if (lane == 0) {
@@ -118,7 +124,7 @@ extern "C" int nerfail_composite(const float* raw, const float* z_vals, const fl
     if (n_rays == 0) return NERFAIL_OK;
     NF_REQUIRE(raw != nullptr && z_vals != nullptr && rays != nullptr, "raw / z_vals / rays is NULL");
     NF_REQUIRE(rgb_map != nullptr && disp_map != nullptr && acc_map != nullptr, "rgb_map / disp_map / acc_map is NULL");
-    NF_REQUIRE((pts == nullptr) == (pts_max == nullptr), "pts and pts_max must be given together");
+    NF_REQUIRE(pts == nullptr || pts_max != nullptr, "pts is only read for pts_max");
     const dim3 block(256), grid((unsigned)((n_rays + 3) / 4));
     const int ipl = (n_samples + 63) / 64;
     hipStream_t s = as_stream(stream);

@@ -189,8 +189,9 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
                                                         const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                                         const int* __restrict__ coarse_cnt, const int* __restrict__ super_cnt, float* __restrict__ dist, float* __restrict__ idx_f,
                                                         int* __restrict__ idx_i) {
-    const long qi = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
+    const long qi_raw = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = qi_raw < nq;                       // (no early return: the far search below is wave-cooperative)
+    const long qi = valid ? qi_raw : nq - 1;
     const Grid g = *gp;
     const int G = g.G;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
@@ -205,25 +206,71 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
     const float ext = g.cs * (float)G;
     const float outside = fmaxf(fmaxf(fmaxf(g.ox - qx, qx - (g.ox + ext)), fmaxf(g.oy - qy, qy - (g.oy + ext))),
                                 fmaxf(g.oz - qz, qz - (g.oz + ext)));
-    const bool skip_shells = outside > (float)(kShellCap + 1) * g.cs;
+    bool skip_shells = outside > (float)(kShellCap + 1) * g.cs;
+    const int Gc = (G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper;
+    if (!skip_shells) {
+        // the 3 x 3 x 3 coarse cells around the query's coarse cell contain every fine cell of shells 0..kShellCap (kShellCap <
+        // kCoarse): if they hold no point (a background pixel's near-plane point in empty space) the shell walk - ~100 dependent
+        // lookups of empty cell ranges - is skipped. 27 independent loads.
+        static_assert(kShellCap < kCoarse, "coarse neighbourhood must cover the shell block");
+        const int CX = cx / kCoarse, CY = cy / kCoarse, CZ = cz / kCoarse;
+        int near = 0;
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int X = min(max(CX + dx, 0), Gc - 1), Y = min(max(CY + dy, 0), Gc - 1), Z = min(max(CZ + dz, 0), Gc - 1);
+                    near |= coarse_cnt[((long)Z * Gc + Y) * Gc + X];
+                }
+        skip_shells = near == 0;
+    }
+    // a cell (or a whole x row of cells) whose box lies farther from the query than the current 8th key cannot change the
+    // result (strict, same 0.999 safety factor as the stopping rule): it is not opened. After shell 0 the 8th distance of a
+    // surface query is a fraction of the cell size, so of the 26 cells of shell 1 only the few the query is close to are
+    // scanned - on view geometry (~100 points per surface cell) that is most of the candidates (round 3).
+    auto cannot_improve_shell = [&](float d2box) {
+        const float md = 0.999f * sqrtf(d2box);
+        return top.d[7] < md * md;
+    };
     for (int R = 0; R < G && R <= kShellCap && !skip_shells; ++R) {
         const int z0 = max(cz - R, 0), z1 = min(cz + R, G - 1);
         const int y0 = max(cy - R, 0), y1 = min(cy + R, G - 1);
         const int x0 = max(cx - R, 0), x1 = min(cx + R, G - 1);
         for (int z = z0; z <= z1; ++z) {
             const bool zface = (z == cz - R) || (z == cz + R);
+            const float cz0 = g.oz + (float)z * g.cs;
+            const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
             for (int y = y0; y <= y1; ++y) {
                 const bool yface = zface || (y == cy - R) || (y == cy + R);
-                // on a z / y face of the shell the whole x row belongs to it (contiguous cells -> one point range);
-                // otherwise only the two end cells x = cx -+ R do
+                const float cy0 = g.oy + (float)y * g.cs;
+                const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
+                const float eyz = ey * ey + ez * ez;
+                if (R > 0 && cannot_improve_shell(eyz)) continue;              // the whole row is too far
+                // on a z / y face of the shell the whole x row belongs to it; otherwise only the two end cells x = cx -+ R do
                 const long row = ((long)z * G + y) * G;
                 if (yface) {
-                    scan_points(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, top);
+                    if (R == 0) {
+                        scan_points(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, top);
+                    } else {
+                        int b = cell_start[row + x0];
+                        for (int x = x0; x <= x1; ++x) {
+                            const int e = cell_start[row + x + 1];
+                            const float cx0 = g.ox + (float)x * g.cs;
+                            const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
+                            if (e > b && !cannot_improve_shell(ex * ex + eyz)) scan_points(sorted, b, e, qx, qy, qz, top);
+                            b = e;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int side = 0; side < 2; ++side) {
                         const int x = side ? cx + R : cx - R;
                         if (x < 0 || x >= G || (side == 1 && R == 0)) continue;
+                        const float cx0 = g.ox + (float)x * g.cs;
+                        const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
+                        if (cannot_improve_shell(ex * ex + eyz)) continue;
                         scan_points(sorted, cell_start[row + x], cell_start[row + x + 1], qx, qy, qz, top);
                     }
                 }
@@ -243,16 +290,23 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
             if (top.d[7] < sb * sb) { done = true; break; } // strict: nothing unvisited can enter or tie
         }
     }
-    if (!done) {
-        // ---- far query (a background pixel's point on the near plane: one to two units from every point, tens of cells):
-        // no shell walk - every block of kSuper^3 coarse cells is RANKED by the distance of its box. The nearest non-empty
-        // block seeds the top-8; after that a block, a coarse cell or a fine cell is opened only if its box can still
-        // hold a point nearer than the current 8th (strict, same 0.999 safety factor as the stopping rule). Every block
-        // is considered, so the result is exact whatever the visiting order (the key (d2, index) is total); walking
-        // coarse SHELLS instead cost ~30 000 empty-cell checks per query (7.7 ms per view).
+    // ---- far queries (background pixels' points on the near plane: one to two units from every point, tens of cells): no shell
+    // walk - the blocks of kSuper^3 coarse cells are RANKED by the distance of their boxes, a block / coarse cell / fine cell
+    // is opened only if its box can still hold a point nearer than the lane's current 8th (strict, same 0.999 safety factor
+    // as the stopping rule). Every block is either opened or excluded by a valid lower bound, so the result is exact whatever
+    // the visiting order (the key (d2, index) is total).
+    // Round 3: the ranking is done by the WAVE for its 64 queries together (they are neighbouring pixels: the same few blocks
+    // matter to all of them). Round 2 let every lane walk all Gs^3 blocks twice on its own: 1000 dependent count loads per
+    // query, 8 ms per view for the 380 000 background queries. Now each lane bounds Gs^3 / 64 blocks against the BOX of the
+    // wave's far queries (a lower bound for each of them), the nearest non-empty block seeds every lane's top-8, and only the
+    // blocks that can still matter to ANY lane (ballot) are walked - by all lanes together, so the count and cell-range
+    // loads are wave-uniform - with the per-lane box tests deciding what each lane actually scans.
+    const bool far = !done;
+    if (__ballot(far) != 0ull) {
+        if (far) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
-        const int Gc = (G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper;
+            for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
+        }
         const float ccs = g.cs * (float)kCoarse, scs = ccs * (float)kSuper;
         auto box_d2 = [&](float x0, float y0, float z0, float size) {      // squared distance from the query to an axis-aligned cube
             const float ddx = fmaxf(fmaxf(x0 - qx, qx - (x0 + size)), 0.f);
@@ -264,52 +318,108 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
             const float md = 0.999f * sqrtf(d2box);
             return top.d[7] < md * md;
         };
+        // Cells are walked from the side of the block that faces the query (per axis: ascending if the query lies below the
+        // block's middle, else descending): the first non-empty cell opened is then among the nearest, the 8th key is tight
+        // after it and the box tests close everything behind. In index order a lane scanned most of a 16^3-cell block - up to
+        // 10^5 points where a base view's near plane crosses it - before its bound became useful.
         auto visit_coarse = [&](int X, int Y, int Z) {                        // the fine cells of one coarse cell, each box-tested
-            const int fx0 = X * kCoarse, fx1 = min(fx0 + kCoarse, G);
-            for (int z = Z * kCoarse; z < min(Z * kCoarse + kCoarse, G); ++z) {
+            const int fx0 = X * kCoarse, fx1 = min(fx0 + kCoarse, G), fy0 = Y * kCoarse, fy1 = min(fy0 + kCoarse, G),
+                      fz0 = Z * kCoarse, fz1 = min(fz0 + kCoarse, G);
+            const bool ux = qx < g.ox + 0.5f * (float)(fx0 + fx1) * g.cs, uy = qy < g.oy + 0.5f * (float)(fy0 + fy1) * g.cs,
+                       uz = qz < g.oz + 0.5f * (float)(fz0 + fz1) * g.cs;
+            for (int kz = 0; kz < fz1 - fz0; ++kz) {
+                const int z = uz ? fz0 + kz : fz1 - 1 - kz;
                 const float cz0 = g.oz + (float)z * g.cs;
                 const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
-                for (int y = Y * kCoarse; y < min(Y * kCoarse + kCoarse, G); ++y) {
+                if (cannot_improve(ez * ez)) continue;                        // (not break: a query inside the cell's extent first gets nearer)
+                for (int ky = 0; ky < fy1 - fy0; ++ky) {
+                    const int y = uy ? fy0 + ky : fy1 - 1 - ky;
                     const float cy0 = g.oy + (float)y * g.cs;
                     const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
                     const float eyz = ey * ey + ez * ez;
+                    if (cannot_improve(eyz)) continue;
                     const long row = ((long)z * G + y) * G;
-                    int b = cell_start[row + fx0];
-                    for (int x = fx0; x < fx1; ++x) {
-                        const int e = cell_start[row + x + 1];
+                    for (int kx = 0; kx < fx1 - fx0; ++kx) {
+                        const int x = ux ? fx0 + kx : fx1 - 1 - kx;
                         const float cx0 = g.ox + (float)x * g.cs;
                         const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
-                        if (e > b && !cannot_improve(ex * ex + eyz)) scan_points(sorted, b, e, qx, qy, qz, top);
-                        b = e;
+                        if (cannot_improve(ex * ex + eyz)) continue;
+                        const int b = cell_start[row + x], e = cell_start[row + x + 1];
+                        if (e > b) scan_points(sorted, b, e, qx, qy, qz, top);
                     }
                 }
             }
         };
         auto visit_super = [&](int SX, int SY, int SZ) {
-            for (int Z = SZ * kSuper; Z < min(SZ * kSuper + kSuper, Gc); ++Z)
-                for (int Y = SY * kSuper; Y < min(SY * kSuper + kSuper, Gc); ++Y)
-                    for (int X = SX * kSuper; X < min(SX * kSuper + kSuper, Gc); ++X) {
+            // a lane that cannot gain from the block as a whole sits the walk out (its box tests would all fail anyway)
+            const bool mine = far && !cannot_improve(box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs));
+            if (__ballot(mine) == 0ull) return;
+            if (!mine) return;
+            const int X0 = SX * kSuper, X1 = min(X0 + kSuper, Gc), Y0 = SY * kSuper, Y1 = min(Y0 + kSuper, Gc),
+                      Z0 = SZ * kSuper, Z1 = min(Z0 + kSuper, Gc);
+            const bool ux = qx < g.ox + 0.5f * (float)(X0 + X1) * ccs, uy = qy < g.oy + 0.5f * (float)(Y0 + Y1) * ccs,
+                       uz = qz < g.oz + 0.5f * (float)(Z0 + Z1) * ccs;
+            for (int kz = 0; kz < Z1 - Z0; ++kz) {
+                const int Z = uz ? Z0 + kz : Z1 - 1 - kz;
+                for (int ky = 0; ky < Y1 - Y0; ++ky) {
+                    const int Y = uy ? Y0 + ky : Y1 - 1 - ky;
+                    for (int kx = 0; kx < X1 - X0; ++kx) {
+                        const int X = ux ? X0 + kx : X1 - 1 - kx;
                         if (coarse_cnt[((long)Z * Gc + Y) * Gc + X] == 0) continue;
                         if (cannot_improve(box_d2(g.ox + (float)X * ccs, g.oy + (float)Y * ccs, g.oz + (float)Z * ccs, ccs))) continue;
                         visit_coarse(X, Y, Z);
                     }
+                }
+            }
         };
-        int best = -1;
+        // box of the wave's far queries
+        const float blx = wave_min(far ? qx : INFINITY), bhx = wave_max(far ? qx : -INFINITY);
+        const float bly = wave_min(far ? qy : INFINITY), bhy = wave_max(far ? qy : -INFINITY);
+        const float blz = wave_min(far ? qz : INFINITY), bhz = wave_max(far ? qz : -INFINITY);
+        auto box_box_d2 = [&](int S) {                                        // lower bound of |q - p| for every far query of the wave, p in block S
+            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
+            const float x0 = g.ox + (float)SX * scs, y0 = g.oy + (float)SY * scs, z0 = g.oz + (float)SZ * scs;
+            const float ddx = fmaxf(fmaxf(x0 - bhx, blx - (x0 + scs)), 0.f);
+            const float ddy = fmaxf(fmaxf(y0 - bhy, bly - (y0 + scs)), 0.f);
+            const float ddz = fmaxf(fmaxf(z0 - bhz, blz - (z0 + scs)), 0.f);
+            return ddx * ddx + ddy * ddy + ddz * ddz;
+        };
+        const int nS = Gs * Gs * Gs;
+        const int lane = threadIdx.x & 63;
+        // 1. the nearest non-empty block (by the wave's box) seeds the top-8 of every far lane
         float best_d2 = INFINITY;
-        for (int S = 0; S < Gs * Gs * Gs; ++S) {
+        int best = 0x7fffffff;
+        for (int S = lane; S < nS; S += 64) {
             if (super_cnt[S] == 0) continue;
-            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
-            const float d2 = box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs);
-            if (d2 < best_d2) { best_d2 = d2; best = S; }
+            const float d2 = box_box_d2(S);
+            if (d2 < best_d2 || (d2 == best_d2 && S < best)) { best_d2 = d2; best = S; }
         }
-        if (best >= 0) visit_super(best % Gs, (best / Gs) % Gs, best / (Gs * Gs));
-        for (int S = 0; S < Gs * Gs * Gs; ++S) {
-            if (S == best || super_cnt[S] == 0) continue;
-            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
-            if (cannot_improve(box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs))) continue;
-            visit_super(SX, SY, SZ);
+        const float wmin = wave_min(best_d2);
+        const unsigned long long at = __ballot(best_d2 == wmin && best != 0x7fffffff);
+        int seed = -1;
+        if (at != 0ull) seed = __shfl(best, __ffsll((long long)at) - 1, 64);
+        if (seed >= 0) visit_super(seed % Gs, (seed / Gs) % Gs, seed / (Gs * Gs));
+        // 2. every other block that can still hold a point nearer than the worst lane's 8th; walked by the whole wave
+        for (int base = 0; base < nS; base += 64) {
+            const float d8max = wave_max(far ? top.d[7] : 0.f);              // (refreshed per batch: the lanes' bounds only shrink)
+            const int S = base + lane;
+            bool cand = S < nS && S != seed && super_cnt[S] != 0;
+            if (cand) {
+                const float md = 0.999f * sqrtf(box_box_d2(S));
+                cand = !(d8max < md * md);
+            }
+            unsigned long long m = __ballot(cand);
+            while (m != 0ull) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const int Sb = base + bit;
+                const int SX = Sb % Gs, SY = (Sb / Gs) % Gs, SZ = Sb / (Gs * Gs);
+                // (a lane that cannot gain from the block skips its cells inside visit_super; the walk itself stays uniform)
+                visit_super(SX, SY, SZ);
+            }
         }
     }
+    if (!valid) return;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         dist[8 * qi + k] = sqrt_rn(top.d[k]);
@@ -350,6 +460,90 @@ extern "C" size_t nerfail_knn8_grid_workspace_bytes(int64_t n_points) {
            al256(super_cells(G) * 4) + al256(knn_cub_temp(n_points));
 }
 
+// The grid of a point set: built once (the set of a scene is fixed - CI:57-61 stacks the base views once, CI:110-163 then
+// walks 400 views against it), searched per view.
+struct GridWs {
+    float* mm; Grid* gp;
+    unsigned *keys_in, *keys_out; int *vals_in, *vals_out;
+    float4* sorted; int *cell_start, *coarse_cnt, *super_cnt;
+    void* temp; size_t temp_bytes;
+    int G;
+};
+static GridWs carve(void* workspace, long n) {
+    GridWs w;
+    const int G = grid_dim_for(n);
+    const long ncells = (long)G * G * G;
+    char* ws = (char*)workspace;
+    w.G = G;
+    w.mm = (float*)ws;
+    w.gp = (Grid*)(ws + 64);
+    ws += al256(256);
+    const size_t seg = al256((size_t)n * 4);
+    w.keys_in = (unsigned*)ws; w.keys_out = (unsigned*)(ws + seg);
+    w.vals_in = (int*)(ws + 2 * seg); w.vals_out = (int*)(ws + 3 * seg);
+    ws += 4 * seg;
+    w.sorted = (float4*)ws; ws += al256((size_t)n * 16);
+    w.cell_start = (int*)ws; ws += al256((size_t)(ncells + 1) * 4);
+    w.coarse_cnt = (int*)ws; ws += al256(coarse_cells(G) * 4);
+    w.super_cnt = (int*)ws; ws += al256(super_cells(G) * 4);
+    w.temp = ws;
+    w.temp_bytes = knn_cub_temp(n);
+    return w;
+}
+
+extern "C" int nerfail_knn8_grid_build(const float* points, int64_t n_points, void* workspace, size_t workspace_bytes, void* stream) {
+    NF_REQUIRE(n_points >= NERFAIL_KNN, "need at least 8 points");
+    NF_REQUIRE(n_points < (1 << 24), "n_points must be < 2^24 (indices are stored as float32, CI:148-163)");
+    NF_REQUIRE(points != nullptr, "NULL pointer");
+    NF_REQUIRE(workspace != nullptr && workspace_bytes >= nerfail_knn8_grid_workspace_bytes(n_points),
+               "workspace too small (nerfail_knn8_grid_workspace_bytes)");
+    hipStream_t s = as_stream(stream);
+    const long n = n_points;
+    const GridWs w = carve(workspace, n);
+    const int G = w.G;
+    const long ncells = (long)G * G * G;
+    bbox_init_kernel<<<dim3(1), dim3(64), 0, s>>>(w.mm);
+    NF_LAUNCHED("bbox_init_kernel");
+    bbox_kernel<<<dim3(256), dim3(256), 0, s>>>(points, n, w.mm);
+    NF_LAUNCHED("bbox_kernel");
+    grid_params_kernel<<<dim3(1), dim3(64), 0, s>>>(w.mm, G, w.gp);
+    NF_LAUNCHED("grid_params_kernel");
+    cell_ids_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(points, n, w.gp, w.keys_in, w.vals_in);
+    NF_LAUNCHED("cell_ids_kernel");
+    int bits = 1;
+    while ((1L << bits) < ncells) ++bits;
+    size_t temp_bytes = w.temp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(w.temp, temp_bytes, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (int)n, 0, bits, s);
+    if (e != hipSuccess) return hip_fail(e, "hipcub::DeviceRadixSort::SortPairs");
+    gather_sorted_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(points, w.vals_out, n, w.sorted);
+    NF_LAUNCHED("gather_sorted_kernel");
+    cell_start_kernel<<<dim3((unsigned)((ncells + 1 + 255) / 256)), dim3(256), 0, s>>>(w.keys_out, n, ncells, w.cell_start);
+    NF_LAUNCHED("cell_start_kernel");
+    const int Gc = (G + kCoarse - 1) / kCoarse;
+    coarse_count_kernel<<<dim3((unsigned)((coarse_cells(G) + 255) / 256)), dim3(256), 0, s>>>(w.cell_start, G, Gc, w.coarse_cnt);
+    NF_LAUNCHED("coarse_count_kernel");
+    const int Gs = (Gc + kSuper - 1) / kSuper;
+    super_count_kernel<<<dim3((unsigned)((super_cells(G) + 255) / 256)), dim3(256), 0, s>>>(w.coarse_cnt, Gc, Gs, w.super_cnt);
+    NF_LAUNCHED("super_count_kernel");
+    return NERFAIL_OK;
+}
+
+extern "C" int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_points, float* dist, float* idx_f32,
+                                        int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream) {
+    NF_REQUIRE(n_queries >= 0, "n_queries is negative");
+    NF_REQUIRE(n_points >= NERFAIL_KNN && n_points < (1 << 24), "bad n_points");
+    if (n_queries == 0) return NERFAIL_OK;
+    NF_REQUIRE(queries != nullptr && dist != nullptr, "NULL pointer");
+    NF_REQUIRE(idx_f32 != nullptr || idx_i32 != nullptr, "need idx_f32 or idx_i32");
+    NF_REQUIRE(workspace != nullptr && workspace_bytes >= nerfail_knn8_grid_workspace_bytes(n_points),
+               "workspace too small (nerfail_knn8_grid_workspace_bytes)");
+    const GridWs w = carve(const_cast<void*>(workspace), n_points);
+    knn8_grid_kernel<<<dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        queries, n_queries, w.gp, w.sorted, w.cell_start, w.coarse_cnt, w.super_cnt, dist, idx_f32, idx_i32);
+    NF_LAUNCHED("knn8_grid_kernel");
+    return NERFAIL_OK;
+}
+
 extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* points, int64_t n_points, float* dist,
                                  float* idx_f32, int32_t* idx_i32, void* workspace, size_t workspace_bytes, void* stream) {
     NF_REQUIRE(n_queries >= 0, "n_queries is negative");
@@ -358,50 +552,7 @@ extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const 
     if (n_queries == 0) return NERFAIL_OK;
     NF_REQUIRE(queries != nullptr && points != nullptr && dist != nullptr, "NULL pointer");
     NF_REQUIRE(idx_f32 != nullptr || idx_i32 != nullptr, "need idx_f32 or idx_i32");
-    NF_REQUIRE(workspace != nullptr && workspace_bytes >= nerfail_knn8_grid_workspace_bytes(n_points),
-               "workspace too small (nerfail_knn8_grid_workspace_bytes)");
-    hipStream_t s = as_stream(stream);
-    const int G = grid_dim_for(n_points);
-    const long ncells = (long)G * G * G, n = n_points;
-    char* ws = (char*)workspace;
-    float* mm = (float*)ws;
-    Grid* gp = (Grid*)(ws + 64);
-    ws += al256(256);
-    const size_t seg = al256((size_t)n * 4);
-    unsigned* keys_in = (unsigned*)ws; unsigned* keys_out = (unsigned*)(ws + seg);
-    int* vals_in = (int*)(ws + 2 * seg); int* vals_out = (int*)(ws + 3 * seg);
-    ws += 4 * seg;
-    float4* sorted = (float4*)ws; ws += al256((size_t)n * 16);
-    int* cell_start = (int*)ws; ws += al256((size_t)(ncells + 1) * 4);
-    int* coarse_cnt = (int*)ws; ws += al256(coarse_cells(G) * 4);
-    int* super_cnt = (int*)ws; ws += al256(super_cells(G) * 4);
-    void* temp = ws;
-    size_t temp_bytes = knn_cub_temp(n);
-
-    bbox_init_kernel<<<dim3(1), dim3(64), 0, s>>>(mm);
-    NF_LAUNCHED("bbox_init_kernel");
-    bbox_kernel<<<dim3(256), dim3(256), 0, s>>>(points, n, mm);
-    NF_LAUNCHED("bbox_kernel");
-    grid_params_kernel<<<dim3(1), dim3(64), 0, s>>>(mm, G, gp);
-    NF_LAUNCHED("grid_params_kernel");
-    cell_ids_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(points, n, gp, keys_in, vals_in);
-    NF_LAUNCHED("cell_ids_kernel");
-    int bits = 1;
-    while ((1L << bits) < ncells) ++bits;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, bits, s);
-    if (e != hipSuccess) return hip_fail(e, "hipcub::DeviceRadixSort::SortPairs");
-    gather_sorted_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(points, vals_out, n, sorted);
-    NF_LAUNCHED("gather_sorted_kernel");
-    cell_start_kernel<<<dim3((unsigned)((ncells + 1 + 255) / 256)), dim3(256), 0, s>>>(keys_out, n, ncells, cell_start);
-    NF_LAUNCHED("cell_start_kernel");
-    const int Gc = (G + kCoarse - 1) / kCoarse;
-    coarse_count_kernel<<<dim3((unsigned)((coarse_cells(G) + 255) / 256)), dim3(256), 0, s>>>(cell_start, G, Gc, coarse_cnt);
-    NF_LAUNCHED("coarse_count_kernel");
-    const int Gs = (Gc + kSuper - 1) / kSuper;
-    super_count_kernel<<<dim3((unsigned)((super_cells(G) + 255) / 256)), dim3(256), 0, s>>>(coarse_cnt, Gc, Gs, super_cnt);
-    NF_LAUNCHED("super_count_kernel");
-    knn8_grid_kernel<<<dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, s>>>(queries, n_queries, gp, sorted, cell_start,
-                                                                                  coarse_cnt, super_cnt, dist, idx_f32, idx_i32);
-    NF_LAUNCHED("knn8_grid_kernel");
-    return NERFAIL_OK;
+    const int rc = nerfail_knn8_grid_build(points, n_points, workspace, workspace_bytes, stream);
+    if (rc != NERFAIL_OK) return rc;
+    return nerfail_knn8_grid_search(queries, n_queries, n_points, dist, idx_f32, idx_i32, workspace, workspace_bytes, stream);
 }

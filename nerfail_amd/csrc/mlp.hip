@@ -217,48 +217,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_kernel(MlpArgs a) {
 
         // ---- B operands of the encoding parts, in registers
         float emb[4 * kEmbQuads], demb[4 * kDirQuads];
-        if (a.xemb == nullptr) {
-            const float px[3] = {a.pts[3 * s], a.pts[3 * s + 1], a.pts[3 * s + 2]};
-            const float* vd = a.viewdirs + 3 * (s / a.spr);
-            const float vx[3] = {vd[0], vd[1], vd[2]};
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const SinCosBands sc(px[d]);           // sin / cos of x * 2^f for all bands, one shared reduction
-#pragma unroll
-                for (int f = 0; f < 10; ++f) {
-                    float sn, cs;
-                    sc.band(f, sn, cs);
-                    emb[3 * f + d] = h ? cs : sn;
-                }
-            }
-            emb[30] = h ? px[1] : px[0];
-            emb[31] = h ? 0.f : px[2];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const SinCosBands sc(vx[d]);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    float sn, cs;
-                    sc.band(f, sn, cs);
-                    demb[3 * f + d] = h ? cs : sn;
-                }
-            }
-            demb[12] = h ? vx[1] : vx[0];
-            demb[13] = h ? 0.f : vx[2];
-            demb[14] = 0.f; demb[15] = 0.f;
-        } else {
-            const float* x = a.xemb + (kPtsCh + kDirCh) * s;
-#pragma unroll
-            for (int st = 0; st < 4 * kEmbQuads; ++st) {
-                const int c = enc_channel(st, h, 10);
-                emb[st] = c >= 0 ? x[c] : 0.f;
-            }
-#pragma unroll
-            for (int st = 0; st < 4 * kDirQuads; ++st) {
-                const int c = enc_channel(st, h, 4);
-                demb[st] = c >= 0 ? x[kPtsCh + c] : 0.f;
-            }
-        }
+        encode_sample(a, s, h, emb, demb);
 
         f32x16 act[NT], acc[NT];
         float* __restrict__ A = nullptr;     // this tile's activation slots (training)
@@ -490,7 +449,7 @@ extern "C" int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, cons
     NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
     if (M == 0) return NERFAIL_OK;
     NF_REQUIRE(packed != nullptr && pts != nullptr && viewdirs != nullptr && raw != nullptr, "NULL pointer");
-    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.raw = raw; a.acts = nullptr; a.M = M; a.spr = samples_per_ray;
+    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.rays = nullptr; a.z = nullptr; a.raw = raw; a.acts = nullptr; a.M = M; a.spr = samples_per_ray;
     return launch_mlp(a, W, as_stream(stream));
 }
 
@@ -501,7 +460,7 @@ extern "C" int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int s
     NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
     if (M == 0) return NERFAIL_OK;
     NF_REQUIRE(packed != nullptr && x != nullptr && raw != nullptr, "NULL pointer");
-    a.packed = packed; a.pts = nullptr; a.viewdirs = nullptr; a.xemb = x; a.raw = raw; a.acts = nullptr; a.M = M; a.spr = 1;
+    a.packed = packed; a.pts = nullptr; a.viewdirs = nullptr; a.xemb = x; a.rays = nullptr; a.z = nullptr; a.raw = raw; a.acts = nullptr; a.M = M; a.spr = 1;
     return launch_mlp(a, W, as_stream(stream));
 }
 
@@ -519,6 +478,22 @@ extern "C" int nerfail_mlp_fwd_train(const float* packed, int D, int W, int skip
     NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
     if (M == 0) return NERFAIL_OK;
     NF_REQUIRE(packed != nullptr && pts != nullptr && viewdirs != nullptr && raw != nullptr && acts != nullptr, "NULL pointer");
-    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.raw = raw; a.acts = acts; a.M = M; a.spr = samples_per_ray;
+    a.packed = packed; a.pts = pts; a.viewdirs = viewdirs; a.xemb = nullptr; a.rays = nullptr; a.z = nullptr; a.raw = raw; a.acts = acts; a.M = M; a.spr = samples_per_ray;
+    return launch_mlp(a, W, as_stream(stream));
+}
+
+// north-star form of the two entry points above: the sample points are formed inside the kernel from the packed rays and the
+// depths (pts = o + d * z, RN:381 / :399) instead of being read from a [M,3] tensor that the sampling kernels wrote.
+extern "C" int nerfail_mlp_fwd_rays(const float* packed, int D, int W, int skip, const float* rays, const float* z_vals,
+                                    int64_t n_rays, int samples_per_ray, float* raw, float* acts, void* stream) {
+    NF_REQUIRE(n_rays >= 0, "n_rays is negative");
+    NF_REQUIRE(samples_per_ray >= 1, "samples_per_ray must be positive");
+    MlpArgs a;
+    NF_REQUIRE(make_layout(D, W, skip, a.lay), "unsupported (D, W)");
+    const int64_t M = n_rays * samples_per_ray;
+    if (M == 0) return NERFAIL_OK;
+    NF_REQUIRE(packed != nullptr && rays != nullptr && z_vals != nullptr && raw != nullptr, "NULL pointer");
+    a.packed = packed; a.pts = nullptr; a.viewdirs = nullptr; a.xemb = nullptr; a.rays = rays; a.z = z_vals; a.raw = raw; a.acts = acts;
+    a.M = M; a.spr = samples_per_ray;
     return launch_mlp(a, W, as_stream(stream));
 }

@@ -105,6 +105,8 @@ struct MlpArgs {
     const float* pts;        // [M,3]      (NULL when xemb is given)
     const float* viewdirs;   // [rays,3]
     const float* xemb;       // [M,90] already embedded input, or NULL
+    const float* rays;       // [rays,11] packed rays (o, d, near, far, viewdir) + z [M]: the point of sample s is formed HERE,
+    const float* z;          //   pts = o + d * z (RN:381 rounding: multiply, then add), and never written to HBM (pts == NULL)
     float* raw;              // [M,4]
     float* acts;             // training only: [tiles][TrainLayout::a_slots][64][16] activations for the backward
     long M;
@@ -118,9 +120,17 @@ int launch_mlp_lds(const MlpArgs& a, int W, hipStream_t s);      // mlp_lds.hip;
 // coordinate, SinCosBands), or gathered from an already embedded input row (NeRF.forward's contract).
 __device__ __forceinline__ void encode_sample(const MlpArgs& a, long s, int h, float (&emb)[4 * kEmbQuads], float (&demb)[4 * kDirQuads]) {
     if (a.xemb == nullptr) {
-        const float px[3] = {a.pts[3 * s], a.pts[3 * s + 1], a.pts[3 * s + 2]};
-        const float* vd = a.viewdirs + 3 * (s / a.spr);
-        const float vx[3] = {vd[0], vd[1], vd[2]};
+        float px[3], vx[3];
+        if (a.rays != nullptr) {         // north-star form: the sample's point from its ray and depth, in registers
+            const float* ray = a.rays + NERFAIL_RAY_FLOATS * (s / a.spr);
+            const float zz = a.z[s];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { px[d] = mul_add_rn(ray[3 + d], zz, ray[d]); vx[d] = ray[8 + d]; }
+        } else {
+            const float* vd = a.viewdirs + 3 * (s / a.spr);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { px[d] = a.pts[3 * s + d]; vx[d] = vd[d]; }
+        }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const SinCosBands sc(px[d]);

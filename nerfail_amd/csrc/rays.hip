@@ -99,8 +99,10 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, long n_rays
         z = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t_rand[g]));
     }
     z_vals[g] = z;
+    if (pts != nullptr) {        // (NULL: the MLP kernel forms the points itself - nerfail_mlp_fwd_rays)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) pts[3 * g + a] = mul_add_rn(ray[3 + a], z, ray[a]);
+        for (int a = 0; a < 3; ++a) pts[3 * g + a] = mul_add_rn(ray[3 + a], z, ray[a]);
+    }
 }
 
 static inline bool fill_cam(Cam& c, const float* K4, const float* c2w) {
@@ -154,7 +156,7 @@ extern "C" int nerfail_sample_coarse(const float* rays, int64_t n_rays, const fl
                                      const float* t_rand, int lindisp, float* z_vals, float* pts, void* stream) {
     NF_REQUIRE(n_rays >= 0 && n_samples > 0, "bad n_rays / n_samples");
     if (n_rays == 0) return NERFAIL_OK;
-    NF_REQUIRE(rays != nullptr && t_vals != nullptr && z_vals != nullptr && pts != nullptr, "NULL pointer");
+    NF_REQUIRE(rays != nullptr && t_vals != nullptr && z_vals != nullptr, "NULL pointer");
     const long n = n_rays * n_samples;
     sample_coarse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
         rays, n_rays, t_vals, n_samples, t_rand, lindisp, z_vals, pts);

@@ -160,12 +160,14 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(const float* __restric
     // bytes (L2 combines the lines). Measured at 640 000 rays: 0.97 ms; staging the sorted row in LDS for 16-byte
     // stores: 1.09 ms (the kernel is instruction-issue bound, ~900 wave instructions per ray, not store bound).
     float* zrow = z_fine + ray * nt;
-    float* prow = pts + 3 * ray * nt;
+    float* prow = pts != nullptr ? pts + 3 * ray * nt : nullptr;     // (NULL: the MLP kernel forms the points itself)
     auto emit = [&](int rank, float z) {
         zrow[rank] = z;
-        prow[3 * rank + 0] = mul_add_rn(dx, z, ox);               // pts = o + d z (RN:399)
-        prow[3 * rank + 1] = mul_add_rn(dy, z, oy);
-        prow[3 * rank + 2] = mul_add_rn(dz, z, oz);
+        if (prow != nullptr) {
+            prow[3 * rank + 0] = mul_add_rn(dx, z, ox);           // pts = o + d z (RN:399)
+            prow[3 * rank + 1] = mul_add_rn(dy, z, oy);
+            prow[3 * rank + 2] = mul_add_rn(dz, z, oz);
+        }
     };
     if (__all(ordered)) {                                                     // wave-uniform
         const int top = 1 << (31 - __clz(max(nc, nf)));
@@ -227,7 +229,7 @@ extern "C" int nerfail_sample_fine(const float* rays, int64_t n_rays, const floa
     NF_REQUIRE(n_fine >= 1 && n_coarse + n_fine <= kMaxMerged - 4, "n_coarse + n_fine too large (max 508)");
     if (n_rays == 0) return NERFAIL_OK;
     NF_REQUIRE(rays != nullptr && z_coarse != nullptr && weights != nullptr && u != nullptr, "NULL input pointer");
-    NF_REQUIRE(z_fine != nullptr && pts != nullptr && z_std != nullptr, "NULL output pointer");
+    NF_REQUIRE(z_fine != nullptr && z_std != nullptr, "NULL output pointer");
     sample_fine_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
         rays, n_rays, z_coarse, weights, n_coarse, u, u_is_row, n_fine, z_samples, z_fine, pts, z_std);
     NF_LAUNCHED("sample_fine_kernel");

@@ -52,6 +52,16 @@ def _mlp_points(fn, pts, viewdirs):
     return raw
 
 
+def _mlp_rays(fn, rays, z_vals, acts=None):
+    """Fused sample-point formation + encode + MLP: packed rays [R,11], z_vals [R,N] -> raw [R,N,4] (nerfail_mlp_fwd_rays: the
+    points o + d z are formed inside the kernel and never touch HBM). acts: the training forward's activation buffer."""
+    R, N = z_vals.shape
+    raw = torch.empty((R, N, 4), dtype=torch.float32, device=z_vals.device)
+    _lib.check(_lib.load().nerfail_mlp_fwd_rays(_lib.dev(fn.packed()), fn.D, fn.W, fn._skip(), _lib.dev(rays, 'rays'),
+                                                _lib.dev(z_vals, 'z_vals'), R, N, _lib.dev(raw), _lib.dev(acts), _lib.stream()))
+    return raw
+
+
 def run_network(inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
     """RN:37-51. With the stock encoders (multires 10 / 4) the encoding and the MLP are one kernel and
     the embedded tensor is never materialised; other encoders go through embed + NeRF.forward."""
@@ -209,19 +219,23 @@ def create_nerf(args):
 
 
 # ----------------------------------------------------------------------------- compositing
-def _composite(raw, z_vals, rays, noise, white_bkgd, pts=None):
+def _composite(raw, z_vals, rays, noise, white_bkgd, pts=None, want_pts_max=None):
+    """pts_max (NC:418-423) is produced when want_pts_max (default: when pts is given); with pts None the kernel forms the
+    point of the largest weight from the ray and its depth."""
     R, N = z_vals.shape
     dev = raw.device
+    if want_pts_max is None:
+        want_pts_max = pts is not None
     rgb_map = torch.empty((R, 3), dtype=torch.float32, device=dev)
     disp_map = torch.empty((R,), dtype=torch.float32, device=dev)
     acc_map = torch.empty((R,), dtype=torch.float32, device=dev)
     weights = torch.empty((R, N), dtype=torch.float32, device=dev)
     depth_map = torch.empty((R,), dtype=torch.float32, device=dev)
-    pts_max = torch.empty((R, 3), dtype=torch.float32, device=dev) if pts is not None else None
+    pts_max = torch.empty((R, 3), dtype=torch.float32, device=dev) if want_pts_max else None
     _lib.check(_lib.load().nerfail_composite(
         _lib.dev(raw, 'raw'), _lib.dev(z_vals, 'z_vals'), _lib.dev(rays, 'rays'), _lib.dev(noise, 'noise'), R, N,
         int(bool(white_bkgd)), _lib.dev(rgb_map), _lib.dev(disp_map), _lib.dev(acc_map), _lib.dev(weights),
-        _lib.dev(depth_map), _lib.dev(pts, 'pts'), _lib.dev(pts_max), _lib.stream()))
+        _lib.dev(depth_map), _lib.dev(pts, 'pts') if want_pts_max else None, _lib.dev(pts_max), _lib.stream()))
     return rgb_map, disp_map, acc_map, weights, depth_map, pts_max
 
 
@@ -333,12 +347,23 @@ def _render_rays_pipeline(rays, network_fn, network_fine, user_query, N_samples,
     def empty():
         return torch.empty((0,), dtype=torch.float32, device=dev)
 
-    def query(p, fn):
+    # The fused exact-f32 path never materialises the sample points: the MLP kernel forms pts = o + d z from the ray and the
+    # depth it already addresses (BASELINE north_star: "fused sample+encode+MLP"). A user-supplied query function and the
+    # opt-in split-precision kernels still receive a [R,N,3] point tensor.
+    def wants_pts(fn):
+        return user_query is not None or getattr(fn, 'precision', 'f32') == 'f16x3'
+
+    def query(p, z, fn):
         if user_query is not None:
             return _lib.f32c(user_query(p, viewdirs, fn), dev), None   # user-supplied query function (reference contract)
         if train:
             from . import _train
-            return _train.mlp_fwd_train(fn, p, viewdirs, acts=acts_for.pop(0) if acts_for else None)
+            a_ = acts_for.pop(0) if acts_for else None
+            if p is None:
+                return _train.mlp_fwd_train_rays(fn, rays, z, acts=a_)
+            return _train.mlp_fwd_train(fn, p, viewdirs, acts=a_)
+        if p is None:
+            return _mlp_rays(fn, rays, z), None                        # points formed in the kernel
         return _mlp_points(fn, p, viewdirs), None                      # fused encode + MLP, nothing materialised
 
     # training: the saved activations of the coarse and the fine pass share ONE buffer (coarse tiles first), so that the
@@ -353,13 +378,13 @@ def _render_rays_pipeline(rays, network_fn, network_fine, user_query, N_samples,
             acts_for = [acts_all[:nc], acts_all[nc:]]
 
     z_vals = torch.empty((R, N_samples), dtype=torch.float32, device=dev)
-    pts = torch.empty((R, N_samples, 3), dtype=torch.float32, device=dev)
+    pts = torch.empty((R, N_samples, 3), dtype=torch.float32, device=dev) if wants_pts(network_fn) else None
     _lib.check(lib.nerfail_sample_coarse(_lib.dev(rays), R, _lib.dev(linspace01(N_samples, dev)), int(N_samples),
                                          _lib.dev(t_rand, 't_rand'), int(bool(lindisp)), _lib.dev(z_vals), _lib.dev(pts), st))
-    raw, acts = query(pts, network_fn)
+    raw, acts = query(pts, z_vals, network_fn)
     last_pass = not (N_importance > 0)
     rgb_map, disp_map, acc_map, weights, depth_map, pts_max = _composite(
-        raw, z_vals, rays, nz, white_bkgd, pts if (want_pts_max and last_pass) else None)
+        raw, z_vals, rays, nz, white_bkgd, pts, want_pts_max and last_pass)
     out = {'rgb0': empty(), 'disp0': empty(), 'acc0': empty(), 'z_std': empty()}
     saved = {'rays': rays, 'coarse': dict(raw=raw, z=z_vals, acts=acts, noise=nz), 'fine': None, 'acts_all': acts_all}
     if N_importance > 0:
@@ -367,16 +392,16 @@ def _render_rays_pipeline(rays, network_fn, network_fine, user_query, N_samples,
         Nt = N_samples + N_importance
         z_samples = torch.empty((R, N_importance), dtype=torch.float32, device=dev)
         z_fine = torch.empty((R, Nt), dtype=torch.float32, device=dev)
-        pts = torch.empty((R, Nt, 3), dtype=torch.float32, device=dev)
+        run_fn = network_fn if network_fine is None else network_fine
+        pts = torch.empty((R, Nt, 3), dtype=torch.float32, device=dev) if wants_pts(run_fn) else None
         z_std = torch.empty((R,), dtype=torch.float32, device=dev)
         _lib.check(lib.nerfail_sample_fine(_lib.dev(rays), R, _lib.dev(z_vals), _lib.dev(weights), int(N_samples),
                                            _lib.dev(u, 'u'), int(u.dim() == 1), int(N_importance), _lib.dev(z_samples),
                                            _lib.dev(z_fine), _lib.dev(pts), _lib.dev(z_std), st))
         z_vals = z_fine
-        run_fn = network_fn if network_fine is None else network_fine
-        raw, acts = query(pts, run_fn)
+        raw, acts = query(pts, z_vals, run_fn)
         rgb_map, disp_map, acc_map, weights, depth_map, pts_max = _composite(
-            raw, z_vals, rays, nzf, white_bkgd, pts if want_pts_max else None)
+            raw, z_vals, rays, nzf, white_bkgd, pts, want_pts_max)
         out['z_std'] = z_std
         saved['fine'] = dict(raw=raw, z=z_vals, acts=acts, noise=nzf)
     out.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map, raw=raw,

@@ -379,3 +379,45 @@ def test_lds_training_forward_saves_the_same_bits_as_the_register_kernel():
                 assert torch.equal(a1[:full], a2[:full]), (D, W, 'acts of the full tiles')
     finally:
         lib.nerfail_mlp_fwd_select(0)
+
+
+def test_points_formed_inside_the_kernel_equal_the_point_tensor_form():
+    """the MLP kernel forms pts = o + d z from the packed ray and the depth (nerfail_mlp_fwd_rays), the
+    sampling kernels stop writing [R,N,3], the composite forms pts_max from the ray. Every output must equal the point-tensor
+    form BITWISE: raw (inference and training forward, both kernels), the saved activations, pts_max."""
+    from nerfail_amd import _lib, _train
+    from nerfail_amd import run_nerf as RN
+    lib = _lib.load()
+    _, net = hip_nerf(8, 256, 17, requires_grad=True)
+    R, Ns = 333, 64
+    rays = T(synth.ray_batch(R, seed=9))
+    rs = np.random.RandomState(9)
+    z = torch.empty((R, Ns), device=dev())
+    pts = torch.empty((R, Ns, 3), device=dev())
+    t_rand = T(rs.uniform(size=(R, Ns)).astype(np.float32))
+    _lib.check(lib.nerfail_sample_coarse(_lib.dev(rays), R, _lib.dev(RN.linspace01(Ns, dev())), Ns, _lib.dev(t_rand), 0, _lib.dev(z),
+                                         _lib.dev(pts), _lib.stream()))
+    z2 = torch.empty_like(z)
+    _lib.check(lib.nerfail_sample_coarse(_lib.dev(rays), R, _lib.dev(RN.linspace01(Ns, dev())), Ns, _lib.dev(t_rand), 0, _lib.dev(z2),
+                                         None, _lib.stream()))                      # pts = NULL: z only
+    assert torch.equal(z, z2)
+    vd = rays[:, 8:11].contiguous()
+    try:
+        for which in (1, 2):
+            lib.nerfail_mlp_fwd_select(which)
+            with torch.no_grad():
+                a = RN._mlp_points(net, pts, vd)
+                b = RN._mlp_rays(net, rays, z)
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), which
+            n_acts = _train.acts_floats(net, R * Ns)         # (pre-filled: a few padding KB per tile are never written)
+            ra, aa = _train.mlp_fwd_train(net, pts, vd, acts=torch.full((n_acts,), float('nan'), device=dev()))
+            rb, ab = _train.mlp_fwd_train_rays(net, rays, z, acts=torch.full((n_acts,), float('nan'), device=dev()))
+            assert torch.equal(ra.view(torch.int32), rb.view(torch.int32)) and torch.equal(ra.view(torch.int32), a.view(torch.int32)), which
+            full = (R * Ns) // 32 * (aa.numel() // ((R * Ns + 31) // 32))
+            assert torch.equal(aa[:full].view(torch.int32), ab[:full].view(torch.int32)), which
+    finally:
+        lib.nerfail_mlp_fwd_select(0)
+    out_p = RN._composite(a, z, rays, None, True, pts, True)
+    out_r = RN._composite(a, z, rays, None, True, None, True)
+    for u, v in zip(out_p, out_r):
+        assert torch.equal(u.view(torch.int32), v.view(torch.int32))
