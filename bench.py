@@ -90,7 +90,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(kernel_substr, which='avg'):
@@ -347,17 +347,32 @@ def knn_bench(dev, reps=2):
     """8-NN index build of ONE view (create_index_and_dist.py:126-145): 640 000 queries (the view's pts_max) against the
     1 920 000-point set of 3 base views. Exact (d2, index) ordering. Two geometries: the synthetic shell points of
     SURVEY.md section 8d, and the analytic pts_max of a rendered sphere (40 % surface hits, 60 % background pixels on
-    the near plane, far from every set point: the case the coarse-cell pruning exists for)."""
+    the near plane, far from every set point). The set's grid is built once per scene (CI:57-61) and searched per view:
+    `ms_per_view` is the per-view search, `grid_build_ms` the one-off build.
+    Roofline: the search is neither HBM- nor MFMA-bound; what it spends is distance evaluations (3 sub, 3 mul, 2 add,
+    no FMA - the bit-exact definition forbids contraction) and the dependent loads that feed them. Reported against the
+    non-FMA vector rate (157.3 / 2 TFLOP/s -> 9.8e12 evaluations/s) with the number of candidates examined per query from
+    the kernel's own counters (nerfail_knn8_grid_stats); the brute-force scan would examine 1 920 000 per query."""
+    from nerfail_amd import _lib, create_index_and_dist as CID
     from nerfail_amd.create_index_and_dist import index_and_dist
+    lib = _lib.load()
     out = {}
     geo = {'shell_points': (synth.sphere_shell_points(3 * H * W, seed=0), synth.sphere_shell_points(H * W, seed=1).reshape(H, W, 3)),
            'rendered_view_geometry': (np.stack([synth.sphere_view_points(H, W, th) for th in (-120., 0., 120.)]).reshape(-1, 3),
                                       synth.sphere_view_points(H, W, 45.).reshape(H, W, 3))}
+    peak_evals = PEAK_F32_MFMA_TFLOPS / 2.0 * 1e12 / 8.0
     for name, (S_, Q_) in geo.items():
         S, Q = torch.from_numpy(np.ascontiguousarray(S_, np.float32)).to(dev), torch.from_numpy(np.ascontiguousarray(Q_, np.float32)).to(dev)
+        CID._GRID.clear()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        CID._grid_for(S)                                         # the build alone
+        e1.record()
+        torch.cuda.synchronize()
+        build_ms = e0.elapsed_time(e1)
         index_and_dist(Q, S)
         blocks = []
-        for _ in range(3):                                       # fastest of 3 blocks of `reps` builds
+        for _ in range(3):                                       # fastest of 3 blocks of `reps` searches
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
@@ -366,12 +381,19 @@ def knn_bench(dev, reps=2):
             torch.cuda.synchronize()
             blocks.append(e0.elapsed_time(e1) / reps * 1e-3)
         dt = min(blocks)
-        alg = 7.68e6 + 23.04e6 + 40.96e6                   # Q + S + out = 71.7 MB per view
-        out[name] = {'views_per_sec': 1.0 / dt, 'ms_per_view': dt * 1e3, 'queries_per_sec': H * W / dt,
+        stats = torch.zeros((2,), dtype=torch.int64, device=dev)
+        lib.nerfail_knn8_grid_stats(_lib.dev(stats))
+        index_and_dist(Q, S)
+        torch.cuda.synchronize()
+        lib.nerfail_knn8_grid_stats(None)
+        cand, nfar = [int(v) for v in stats.cpu().tolist()]
+        out[name] = {'views_per_sec': 1.0 / dt, 'ms_per_view': dt * 1e3, 'queries_per_sec': H * W / dt, 'grid_build_ms': build_ms,
+                     'candidates_examined_per_query': cand / float(H * W), 'far_search_queries': nfar,
                      'brute_force_equivalent_pairs_per_sec': float(H * W) * float(3 * H * W) / dt,
-                     'roofline': {'bound': 'hbm', 'achieved': alg / dt / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                  'frac': alg / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                                  'note': 'grid build (count / scan / scatter) + search; the search is latency / VALU bound, not HBM'}}
+                     'roofline': {'bound': 'valu', 'achieved': cand / dt / 1e12, 'peak': peak_evals / 1e12,
+                                  'unit': '1e12 distance evaluations/s (8 non-FMA flops each)', 'frac': cand / dt / peak_evals, 'traffic': None,
+                                  'note': 'latency bound: the evaluations are fed by dependent cell-range and point loads; '
+                                          'compulsory HBM traffic is 71.7 MB per view (%.1f GB/s at this rate)' % (71.7e6 / dt / 1e9)}}
     out.update(out['shell_points'])                          # round-1 keys keep their meaning (shell points)
     return out
 

@@ -237,6 +237,10 @@ int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* poin
 int nerfail_knn8_grid_build(const float* points, int64_t n_points, void* workspace, size_t workspace_bytes, void* stream);
 int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_points, float* dist, float* idx_f32,
                              int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream);
+/* Work counters of the grid search (measurement aid, off by default): while `stats` (two device uint64, zeroed by the caller)
+ * is set, every search adds [0] the candidate points it computed a distance to and [1] the queries that needed the far
+ * search. NULL switches the counters off again. Process-wide, not stream-ordered with other threads' searches. */
+int nerfail_knn8_grid_stats(unsigned long long* stats);
 
 /* ------------------------------------------------------------------ gauss path (K9-K12) --- */
 
