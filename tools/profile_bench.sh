@@ -7,13 +7,14 @@
 # The program stands directly behind `--` (no env / bash -c hop: the profiler has initialised the GPU by then).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r03
-rm -rf $O && mkdir -p $O
+mkdir -p $O && rm -rf $O/stats $O/pmc_fetch $O/pmc_write
 export NERFAIL_BENCH_TUNE_VICTIM=${NERFAIL_BENCH_TUNE_VICTIM:-1}
 timeout -k 10 420 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err || exit 1
 echo "bench line done" && tail -c 300 $O/bench_line.json
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_line_under_rocprof.json 2> $O/rocprof_stats.log || exit 1
 echo "stats pass done"
 export NERFAIL_BENCH_TUNE_VICTIM=0
+export NERFAIL_BENCH_LIGHT=1
 PMC_CMD="bench.py --steps 1 --warmup 0 --no-cpu-baseline --sections render,train,attack"
 timeout -k 10 560 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $PMC_CMD > $O/pmc_fetch.json 2> $O/pmc_fetch.log || exit 1
 echo "fetch pass done"
