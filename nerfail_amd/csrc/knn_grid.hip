@@ -305,90 +305,183 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
     // loads are wave-uniform - with the per-lane box tests deciding what each lane actually scans.
     const bool far = !done;
     if (__ballot(far) != 0ull) {
-        if (far) {
+        // The far search keeps a lane's 8 keys as packed 64-bit integers (float32 bits of d2, non-negative, in the high word,
+        // the point index in the low word): unsigned integer order == the lexicographic (d2, index) order of the brute-force
+        // kernel, one compare per test, and a sorted insert is 8 compare-exchange steps without branches.
+        typedef unsigned long long Key;
+        constexpr Key kNoKey = ~0ull;                                        // (d2 bits 0xffffffff: not a distance)
+        Key fk[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
-        }
+        for (int k = 0; k < 8; ++k) fk[k] = ((Key)0x7f800000u << 32) | 0x7fffffffu;
+        Key pend = kNoKey;                                                   // one candidate waiting to be inserted (below)
+        auto d8 = [&]() { return __uint_as_float((unsigned)(fk[7] >> 32)); };
+        auto insert_key = [&](Key k) {                                       // fk stays sorted; the largest of the 9 keys drops out
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool c = k < fk[i];
+                const Key lo = c ? k : fk[i];
+                k = c ? fk[i] : k;
+                fk[i] = lo;
+            }
+        };
+        // Round 3, second step: the WHOLE walk is wave-uniform. Blocks, coarse cells, fine cells and candidate points are
+        // visited by the wave in one common order (all indices live in scalar registers: counts, cell ranges and the points
+        // themselves arrive through scalar loads, no vector memory traffic at all); a lane only contributes its own box tests
+        // - "can this box still hold a point nearer than MY 8th?" - and a box is opened when ANY far lane says yes (ballot).
+        // Every far lane then measures every point the wave opens: extra candidates never change an exact result, the lanes'
+        // bounds tighten together, and 64 neighbouring pixels' searches cost one instruction stream instead of 64 divergent
+        // chains of dependent loads (per-lane walk inside the blocks: 6.1 ms of the 6.7 ms view).
         const float ccs = g.cs * (float)kCoarse, scs = ccs * (float)kSuper;
-        auto box_d2 = [&](float x0, float y0, float z0, float size) {      // squared distance from the query to an axis-aligned cube
-            const float ddx = fmaxf(fmaxf(x0 - qx, qx - (x0 + size)), 0.f);
-            const float ddy = fmaxf(fmaxf(y0 - qy, qy - (y0 + size)), 0.f);
-            const float ddz = fmaxf(fmaxf(z0 - qz, qz - (z0 + size)), 0.f);
+        auto uni_f = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        auto any_needs = [&](float d2box) {                                  // does any far lane still need a box at this distance?
+            const float md = 0.999f * sqrtf(d2box);
+            return __ballot(far && !(d8() < md * md)) != 0ull;
+        };
+        auto axis_d = [](float lo, float size, float q) { return fmaxf(fmaxf(lo - q, q - (lo + size)), 0.f); };
+        // box of the wave's far queries; its centre decides the (uniform) direction the cells of a block are walked in
+        const float blx = uni_f(wave_min(far ? qx : INFINITY)), bhx = uni_f(wave_max(far ? qx : -INFINITY));
+        const float bly = uni_f(wave_min(far ? qy : INFINITY)), bhy = uni_f(wave_max(far ? qy : -INFINITY));
+        const float blz = uni_f(wave_min(far ? qz : INFINITY)), bhz = uni_f(wave_max(far ? qz : -INFINITY));
+        const float wx = 0.5f * (blx + bhx), wy = 0.5f * (bly + bhy), wz = 0.5f * (blz + bhz);
+        const int lane = threadIdx.x & 63;
+        auto lane_i = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+        auto lane_f = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        auto wave_box_d2 = [&](float x0, float y0, float z0, float size) {   // lower bound of |q - p|, p in the cube, for EVERY far query of the wave
+            const float ddx = fmaxf(fmaxf(x0 - bhx, blx - (x0 + size)), 0.f);
+            const float ddy = fmaxf(fmaxf(y0 - bhy, bly - (y0 + size)), 0.f);
+            const float ddz = fmaxf(fmaxf(z0 - bhz, blz - (z0 + size)), 0.f);
             return ddx * ddx + ddy * ddy + ddz * ddz;
         };
-        auto cannot_improve = [&](float d2box) {                              // lower bound of the box, shrunk by the safety factor
-            const float md = 0.999f * sqrtf(d2box);
-            return top.d[7] < md * md;
+        auto wave_d8max = [&]() { return uni_f(wave_max(far ? d8() : 0.f)); };
+        // Candidates [b, e) (uniform) against every far lane's top-8: the 64 lanes fetch 64 consecutive points with ONE load
+        // (1 KB, coalesced), then point j is broadcast from lane j's registers (v_readlane) - one memory round trip per 64
+        // candidates (scalar loads, 4 points per round trip, left the wave waiting ~400 cycles per candidate).
+        // A candidate that passes a lane's threshold is only PARKED in the lane's one-entry `pend`; the sorted insert runs for
+        // the whole wave at once when some lane needs its slot again (and at the end of the cell). With 64 lanes almost every
+        // candidate improved SOME lane, and the wave paid a masked insert (~40 % of the time of this loop) nearly every
+        // iteration; parked, the wave inserts a few hundred times per search instead of a few thousand. A parked key leaves
+        // the threshold stale (too large) until it is inserted: more candidates pass, none is lost.
+        auto flush = [&]() {
+            if (pend != kNoKey) insert_key(pend);
+            pend = kNoKey;
         };
-        // Cells are walked from the side of the block that faces the query (per axis: ascending if the query lies below the
-        // block's middle, else descending): the first non-empty cell opened is then among the nearest, the 8th key is tight
-        // after it and the box tests close everything behind. In index order a lane scanned most of a 16^3-cell block - up to
-        // 10^5 points where a base view's near plane crosses it - before its bound became useful.
-        auto visit_coarse = [&](int X, int Y, int Z) {                        // the fine cells of one coarse cell, each box-tested
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        auto scan_uniform = [&](int b, int e) {
+            if (far) examined += (unsigned)(e - b);
+            for (int p0 = b; p0 < e; p0 += 64) {
+                const int n = min(64, e - p0);
+                const float4 mine = sorted[min(p0 + lane, e - 1)];
+                // Four candidates per trip, as two float pairs (v_pk_* arithmetic, no contraction), filtered by ONE float compare
+                // each against the lane's 8th distance (<=: ties are settled on the packed key below); the point index is only
+                // fetched for candidates that pass. ~8 vector instructions per candidate where the first form of this loop had 20.
+                for (int j = 0; j < n; j += 4) {
+                    const float d8f = d8();
+                    f32x2 d2p[2];
+                    bool any = false;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int l0 = min(j + 2 * h, n - 1), l1 = min(j + 2 * h + 1, n - 1);
+                        const f32x2 px = {lane_f(mine.x, l0), lane_f(mine.x, l1)}, py = {lane_f(mine.y, l0), lane_f(mine.y, l1)},
+                                    pz = {lane_f(mine.z, l0), lane_f(mine.z, l1)};
+                        const f32x2 dx = qx2 - px, dy = qy2 - py, dz = qz2 - pz;
+                        d2p[h] = (dx * dx + dy * dy) + dz * dz;
+                        any |= (d2p[h].x <= d8f) | (d2p[h].y <= d8f);
+                    }
+                    if (__ballot(far & any) == 0ull) continue;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u >= n) break;
+                        const unsigned id = (unsigned)lane_i(__float_as_int(mine.w), j + u);
+                        const Key key = ((Key)__float_as_uint(u & 1 ? d2p[u >> 1].y : d2p[u >> 1].x) << 32) | id;
+                        bool p = far & (key < fk[7]);
+                        if (__ballot(p & (pend != kNoKey)) != 0ull) {
+                            flush();
+                            p = p & (key < fk[7]);
+                        }
+                        if (p) pend = key;
+                    }
+                }
+            }
+            if (__ballot(pend != kNoKey) != 0ull) flush();
+        };
+        // A 4 x 4 x 4 group of boxes is looked at by the 64 lanes together, lane = box: lane bits (z, y, x) count from the side
+        // of the group that faces the wave's queries, so ascending lane order opens the nearest boxes first (the 8th keys are
+        // tight after the first non-empty one and the box tests close everything behind).
+        // One coarse cell: lane = fine cell; its point range arrives with two loads per wave (one round trip, where a loop over
+        // the cells waited for 64 dependent loads), the wave-box bound drops most cells in parallel, the rest are tested exactly.
+        auto visit_coarse = [&](int X, int Y, int Z) {
             const int fx0 = X * kCoarse, fx1 = min(fx0 + kCoarse, G), fy0 = Y * kCoarse, fy1 = min(fy0 + kCoarse, G),
                       fz0 = Z * kCoarse, fz1 = min(fz0 + kCoarse, G);
-            const bool ux = qx < g.ox + 0.5f * (float)(fx0 + fx1) * g.cs, uy = qy < g.oy + 0.5f * (float)(fy0 + fy1) * g.cs,
-                       uz = qz < g.oz + 0.5f * (float)(fz0 + fz1) * g.cs;
-            for (int kz = 0; kz < fz1 - fz0; ++kz) {
-                const int z = uz ? fz0 + kz : fz1 - 1 - kz;
-                const float cz0 = g.oz + (float)z * g.cs;
-                const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
-                if (cannot_improve(ez * ez)) continue;                        // (not break: a query inside the cell's extent first gets nearer)
-                for (int ky = 0; ky < fy1 - fy0; ++ky) {
-                    const int y = uy ? fy0 + ky : fy1 - 1 - ky;
-                    const float cy0 = g.oy + (float)y * g.cs;
-                    const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
-                    const float eyz = ey * ey + ez * ez;
-                    if (cannot_improve(eyz)) continue;
-                    const long row = ((long)z * G + y) * G;
-                    for (int kx = 0; kx < fx1 - fx0; ++kx) {
-                        const int x = ux ? fx0 + kx : fx1 - 1 - kx;
-                        const float cx0 = g.ox + (float)x * g.cs;
-                        const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
-                        if (cannot_improve(ex * ex + eyz)) continue;
-                        const int b = cell_start[row + x], e = cell_start[row + x + 1];
-                        if (e > b) scan_points(sorted, b, e, qx, qy, qz, top, examined);
-                    }
-                }
+            const bool ux = wx < g.ox + 0.5f * (float)(fx0 + fx1) * g.cs, uy = wy < g.oy + 0.5f * (float)(fy0 + fy1) * g.cs,
+                       uz = wz < g.oz + 0.5f * (float)(fz0 + fz1) * g.cs;
+            auto cell_of = [&](int l, int& x, int& y, int& z) {
+                const int kx = l & 3, ky = (l >> 2) & 3, kz = l >> 4;
+                x = ux ? fx0 + kx : fx1 - 1 - kx; y = uy ? fy0 + ky : fy1 - 1 - ky; z = uz ? fz0 + kz : fz1 - 1 - kz;
+                return x >= fx0 && x < fx1 && y >= fy0 && y < fy1 && z >= fz0 && z < fz1;
+            };
+            int x, y, z, cb = 0, ce = 0;
+            if (cell_of(lane, x, y, z)) {
+                const long at = ((long)z * G + y) * G + x;
+                cb = cell_start[at]; ce = cell_start[at + 1];
+            }
+            const float d8max = wave_d8max();                                 // (all lanes: a cross-lane reduction)
+            bool cand = ce > cb;
+            if (cand) {
+                const float md = 0.999f * sqrtf(wave_box_d2(g.ox + (float)x * g.cs, g.oy + (float)y * g.cs, g.oz + (float)z * g.cs, g.cs));
+                cand = !(d8max < md * md);
+            }
+            unsigned long long m = __ballot(cand);
+            while (m != 0ull) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                int ux_, uy_, uz_;
+                cell_of(bit, ux_, uy_, uz_);
+                const float ex = axis_d(g.ox + (float)ux_ * g.cs, g.cs, qx), ey = axis_d(g.oy + (float)uy_ * g.cs, g.cs, qy),
+                            ez = axis_d(g.oz + (float)uz_ * g.cs, g.cs, qz);
+                if (!any_needs(ex * ex + ey * ey + ez * ez)) continue;
+                scan_uniform(lane_i(cb, bit), lane_i(ce, bit));
             }
         };
-        auto visit_super = [&](int SX, int SY, int SZ) {
-            // a lane that cannot gain from the block as a whole sits the walk out (its box tests would all fail anyway)
-            const bool mine = far && !cannot_improve(box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs));
-            if (__ballot(mine) == 0ull) return;
-            if (!mine) return;
-            const int X0 = SX * kSuper, X1 = min(X0 + kSuper, Gc), Y0 = SY * kSuper, Y1 = min(Y0 + kSuper, Gc),
-                      Z0 = SZ * kSuper, Z1 = min(Z0 + kSuper, Gc);
-            const bool ux = qx < g.ox + 0.5f * (float)(X0 + X1) * ccs, uy = qy < g.oy + 0.5f * (float)(Y0 + Y1) * ccs,
-                       uz = qz < g.oz + 0.5f * (float)(Z0 + Z1) * ccs;
-            for (int kz = 0; kz < Z1 - Z0; ++kz) {
-                const int Z = uz ? Z0 + kz : Z1 - 1 - kz;
-                for (int ky = 0; ky < Y1 - Y0; ++ky) {
-                    const int Y = uy ? Y0 + ky : Y1 - 1 - ky;
-                    for (int kx = 0; kx < X1 - X0; ++kx) {
-                        const int X = ux ? X0 + kx : X1 - 1 - kx;
-                        if (coarse_cnt[((long)Z * Gc + Y) * Gc + X] == 0) continue;
-                        if (cannot_improve(box_d2(g.ox + (float)X * ccs, g.oy + (float)Y * ccs, g.oz + (float)Z * ccs, ccs))) continue;
-                        visit_coarse(X, Y, Z);
-                    }
-                }
-            }
-        };
-        // box of the wave's far queries
-        const float blx = wave_min(far ? qx : INFINITY), bhx = wave_max(far ? qx : -INFINITY);
-        const float bly = wave_min(far ? qy : INFINITY), bhy = wave_max(far ? qy : -INFINITY);
-        const float blz = wave_min(far ? qz : INFINITY), bhz = wave_max(far ? qz : -INFINITY);
-        auto box_box_d2 = [&](int S) {                                        // lower bound of |q - p| for every far query of the wave, p in block S
-            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
-            const float x0 = g.ox + (float)SX * scs, y0 = g.oy + (float)SY * scs, z0 = g.oz + (float)SZ * scs;
-            const float ddx = fmaxf(fmaxf(x0 - bhx, blx - (x0 + scs)), 0.f);
-            const float ddy = fmaxf(fmaxf(y0 - bhy, bly - (y0 + scs)), 0.f);
-            const float ddz = fmaxf(fmaxf(z0 - bhz, blz - (z0 + scs)), 0.f);
+        auto box_d2 = [&](float x0, float y0, float z0, float size) {      // squared distance from the lane's query to an axis-aligned cube
+            const float ddx = axis_d(x0, size, qx), ddy = axis_d(y0, size, qy), ddz = axis_d(z0, size, qz);
             return ddx * ddx + ddy * ddy + ddz * ddz;
         };
+        auto visit_super = [&](int S) {                                       // lane = coarse cell of the block
+            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
+            if (!any_needs(box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs))) return;
+            const int X0 = SX * kSuper, X1 = min(X0 + kSuper, Gc), Y0 = SY * kSuper, Y1 = min(Y0 + kSuper, Gc),
+                      Z0 = SZ * kSuper, Z1 = min(Z0 + kSuper, Gc);
+            const bool ux = wx < g.ox + 0.5f * (float)(X0 + X1) * ccs, uy = wy < g.oy + 0.5f * (float)(Y0 + Y1) * ccs,
+                       uz = wz < g.oz + 0.5f * (float)(Z0 + Z1) * ccs;
+            auto cell_of = [&](int l, int& Xc, int& Yc, int& Zc) {
+                const int kx = l & 3, ky = (l >> 2) & 3, kz = l >> 4;
+                Xc = ux ? X0 + kx : X1 - 1 - kx; Yc = uy ? Y0 + ky : Y1 - 1 - ky; Zc = uz ? Z0 + kz : Z1 - 1 - kz;
+                return Xc >= X0 && Xc < X1 && Yc >= Y0 && Yc < Y1 && Zc >= Z0 && Zc < Z1;
+            };
+            int Xc, Yc, Zc;
+            const float d8max = wave_d8max();                                 // (all lanes: a cross-lane reduction)
+            bool cand = cell_of(lane, Xc, Yc, Zc) && coarse_cnt[((long)Zc * Gc + Yc) * Gc + Xc] != 0;
+            if (cand) {
+                const float md = 0.999f * sqrtf(wave_box_d2(g.ox + (float)Xc * ccs, g.oy + (float)Yc * ccs, g.oz + (float)Zc * ccs, ccs));
+                cand = !(d8max < md * md);
+            }
+            unsigned long long m = __ballot(cand);
+            while (m != 0ull) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                int Xu, Yu, Zu;
+                cell_of(bit, Xu, Yu, Zu);
+                if (!any_needs(box_d2(g.ox + (float)Xu * ccs, g.oy + (float)Yu * ccs, g.oz + (float)Zu * ccs, ccs))) continue;
+                visit_coarse(Xu, Yu, Zu);
+            }
+        };
+        auto box_box_d2 = [&](int S) {
+            const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
+            return wave_box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs);
+        };
         const int nS = Gs * Gs * Gs;
-        const int lane = threadIdx.x & 63;
-        // 1. the nearest non-empty block (by the wave's box) seeds the top-8 of every far lane
+        // 1. the nearest non-empty block (by the wave's box) seeds the top-8 of every far lane (each lane ranks nS / 64 blocks)
         float best_d2 = INFINITY;
         int best = 0x7fffffff;
         for (int S = lane; S < nS; S += 64) {
@@ -399,11 +492,11 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
         const float wmin = wave_min(best_d2);
         const unsigned long long at = __ballot(best_d2 == wmin && best != 0x7fffffff);
         int seed = -1;
-        if (at != 0ull) seed = __shfl(best, __ffsll((long long)at) - 1, 64);
-        if (seed >= 0) visit_super(seed % Gs, (seed / Gs) % Gs, seed / (Gs * Gs));
-        // 2. every other block that can still hold a point nearer than the worst lane's 8th; walked by the whole wave
+        if (at != 0ull) seed = __builtin_amdgcn_readfirstlane(__shfl(best, __ffsll((long long)at) - 1, 64));
+        if (seed >= 0) visit_super(seed);
+        // 2. every other block that can still hold a point nearer than the worst lane's 8th
         for (int base = 0; base < nS; base += 64) {
-            const float d8max = wave_max(far ? top.d[7] : 0.f);              // (refreshed per batch: the lanes' bounds only shrink)
+            const float d8max = wave_max(far ? d8() : 0.f);                  // (refreshed per batch: the lanes' bounds only shrink)
             const int S = base + lane;
             bool cand = S < nS && S != seed && super_cnt[S] != 0;
             if (cand) {
@@ -414,11 +507,12 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
             while (m != 0ull) {
                 const int bit = __ffsll((long long)m) - 1;
                 m &= m - 1ull;
-                const int Sb = base + bit;
-                const int SX = Sb % Gs, SY = (Sb / Gs) % Gs, SZ = Sb / (Gs * Gs);
-                // (a lane that cannot gain from the block skips its cells inside visit_super; the walk itself stays uniform)
-                visit_super(SX, SY, SZ);
+                visit_super(base + bit);
             }
+        }
+        if (far) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { top.d[k] = __uint_as_float((unsigned)(fk[k] >> 32)); top.i[k] = (int)(unsigned)fk[k]; }
         }
     }
     if (stats != nullptr) {             // [0] candidates examined, [1] queries that took the far search (one atomic per wave)
