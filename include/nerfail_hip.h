@@ -237,6 +237,11 @@ int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* poin
 int nerfail_knn8_grid_build(const float* points, int64_t n_points, void* workspace, size_t workspace_bytes, void* stream);
 int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_points, float* dist, float* idx_f32,
                              int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream);
+/* The same search for the [height, width, 3] point image of ONE VIEW (pts_max, NC:418-423 -> CI:126): results in the same
+ * row-major [height*width, 8] layout, but a wave searches an 8 x 8 pixel tile instead of 64 consecutive pixels of a row -
+ * neighbouring pixels' points lie within a fraction of a grid cell, the 64 searches share their candidates. */
+int nerfail_knn8_grid_search_view(const float* queries, int height, int width, int64_t n_points, float* dist, float* idx_f32,
+                                  int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream);
 /* Work counters of the grid search (measurement aid, off by default): while `stats` (two device uint64, zeroed by the caller)
  * is set, every search adds [0] the candidate points it computed a distance to and [1] the queries that needed the far
  * search. NULL switches the counters off again. Process-wide, not stream-ordered with other threads' searches. */

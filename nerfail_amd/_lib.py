@@ -79,6 +79,7 @@ SIGNATURES = {
     'nerfail_knn8_grid_build': (c_i, [c_p, c_i64, c_p, ctypes.c_size_t, c_p]),
     'nerfail_knn8_grid_stats': (c_i, [c_p]),
     'nerfail_knn8_grid_search': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    'nerfail_knn8_grid_search_view': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),

@@ -36,8 +36,12 @@ def knn8(queries, points, want_int=False, method='auto'):
         method = 'grid' if p.shape[0] >= 4096 else 'brute'
     if method == 'grid':
         ws, nbytes = _grid_for(p)
-        _lib.check(lib.nerfail_knn8_grid_search(_lib.dev(q2, 'queries'), q2.shape[0], p.shape[0], _lib.dev(dist), idx_f, idx_i,
-                                                _lib.dev(ws), nbytes, _lib.stream()))
+        if q.dim() == 3 and q.shape[0] >= 8 and q.shape[1] >= 8:          # a view's point image: waves take 8 x 8 pixel tiles
+            _lib.check(lib.nerfail_knn8_grid_search_view(_lib.dev(q2, 'queries'), q.shape[0], q.shape[1], p.shape[0], _lib.dev(dist),
+                                                         idx_f, idx_i, _lib.dev(ws), nbytes, _lib.stream()))
+        else:
+            _lib.check(lib.nerfail_knn8_grid_search(_lib.dev(q2, 'queries'), q2.shape[0], p.shape[0], _lib.dev(dist), idx_f, idx_i,
+                                                    _lib.dev(ws), nbytes, _lib.stream()))
     elif method == 'brute':
         _lib.check(lib.nerfail_knn8(_lib.dev(q2, 'queries'), q2.shape[0], _lib.dev(p, 'points'), p.shape[0],
                                     _lib.dev(dist), idx_f, idx_i, _lib.stream()))

@@ -186,13 +186,43 @@ __device__ __forceinline__ void scan_points(const float4* __restrict__ sorted, i
     }
 }
 
-__global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict__ queries, long nq, const Grid* __restrict__ gp,
+// wave-wide min / max on DPP moves (row_shr 1/2/4/8, row_bcast 15/31: an inclusive scan whose lane 63 holds the total),
+// broadcast by v_readlane: the result is wave-uniform (an SGPR). __shfl_xor is ds_bpermute_b32 on gfx9 - six dependent trips
+// through the LDS crossbar per reduction. NaN-free inputs.
+template <int CTRL, int ROW_MASK, bool MAX>
+__device__ __forceinline__ float dpp_minmax_step(float v) {
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(MAX ? (int)0xff800000 : 0x7f800000, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+    return MAX ? fmaxf(v, o) : fminf(v, o);
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_uniform(float v) {
+    v = dpp_minmax_step<0x111, 0xF, MAX>(v); v = dpp_minmax_step<0x112, 0xF, MAX>(v); v = dpp_minmax_step<0x114, 0xF, MAX>(v);
+    v = dpp_minmax_step<0x118, 0xF, MAX>(v); v = dpp_minmax_step<0x142, 0xA, MAX>(v); v = dpp_minmax_step<0x143, 0xC, MAX>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+constexpr int kCoherentCells = 6;     // a wave whose queries span at most this many cells per axis searches as ONE (see below)
+
+__global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__ queries, long nq, int view_h, int view_w, const Grid* __restrict__ gp,
                                                         const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                                         const int* __restrict__ coarse_cnt, const int* __restrict__ super_cnt, float* __restrict__ dist, float* __restrict__ idx_f,
                                                         int* __restrict__ idx_i, unsigned long long* __restrict__ stats) {
-    const long qi_raw = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = qi_raw < nq;                       // (no early return: the far search below is wave-cooperative)
-    const long qi = valid ? qi_raw : nq - 1;
+    // One wave per workgroup. view_w > 0: the queries are the [view_h, view_w] pixels of a view and a wave takes an 8 x 8 pixel
+    // TILE (0.014 scene units across on a lego view, a third of a cell: the 64 searches share nearly all their candidates);
+    // view_w == 0: 64 consecutive queries. Lanes past the end repeat a valid query of the wave (no early return: the search
+    // below is wave-cooperative) and store nothing.
+    bool valid;
+    long qi;
+    if (view_w > 0) {
+        const int tiles_x = (view_w + 7) >> 3;
+        const int row = (int)(blockIdx.x / tiles_x) * 8 + (int)(threadIdx.x >> 3), col = (int)(blockIdx.x % tiles_x) * 8 + (int)(threadIdx.x & 7);
+        valid = row < view_h && col < view_w;
+        qi = (long)min(row, view_h - 1) * view_w + min(col, view_w - 1);
+    } else {
+        const long qi_raw = (long)blockIdx.x * 64 + threadIdx.x;
+        valid = qi_raw < nq;
+        qi = valid ? qi_raw : nq - 1;
+    }
     const Grid g = *gp;
     const int G = g.G;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
@@ -209,6 +239,13 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
     const float outside = fmaxf(fmaxf(fmaxf(g.ox - qx, qx - (g.ox + ext)), fmaxf(g.oy - qy, qy - (g.oy + ext))),
                                 fmaxf(g.oz - qz, qz - (g.oz + ext)));
     bool skip_shells = outside > (float)(kShellCap + 1) * g.cs;
+    // The 64 queries of a wave are neighbouring pixels of a view: when they lie within a few cells of each other (they do
+    // except across silhouettes and image rows) the wave searches for all of them TOGETHER (below): one instruction stream,
+    // coalesced loads, shared candidates. Only waves of scattered queries take the per-lane shell walk first.
+    const float wex = wave_minmax_uniform<true>(qx) - wave_minmax_uniform<false>(qx), wey = wave_minmax_uniform<true>(qy) - wave_minmax_uniform<false>(qy),
+                wez = wave_minmax_uniform<true>(qz) - wave_minmax_uniform<false>(qz);
+    const bool coherent = fmaxf(fmaxf(wex, wey), wez) <= (float)kCoherentCells * g.cs;
+    skip_shells = skip_shells || coherent;
     const int Gc = (G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper;
     if (!skip_shells) {
         // the 3 x 3 x 3 coarse cells around the query's coarse cell contain every fine cell of shells 0..kShellCap (kShellCap <
@@ -332,17 +369,15 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
         // bounds tighten together, and 64 neighbouring pixels' searches cost one instruction stream instead of 64 divergent
         // chains of dependent loads (per-lane walk inside the blocks: 6.1 ms of the 6.7 ms view).
         const float ccs = g.cs * (float)kCoarse, scs = ccs * (float)kSuper;
-        auto uni_f = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
         auto any_needs = [&](float d2box) {                                  // does any far lane still need a box at this distance?
             const float md = 0.999f * sqrtf(d2box);
             return __ballot(far && !(d8() < md * md)) != 0ull;
         };
         auto axis_d = [](float lo, float size, float q) { return fmaxf(fmaxf(lo - q, q - (lo + size)), 0.f); };
-        // box of the wave's far queries; its centre decides the (uniform) direction the cells of a block are walked in
-        const float blx = uni_f(wave_min(far ? qx : INFINITY)), bhx = uni_f(wave_max(far ? qx : -INFINITY));
-        const float bly = uni_f(wave_min(far ? qy : INFINITY)), bhy = uni_f(wave_max(far ? qy : -INFINITY));
-        const float blz = uni_f(wave_min(far ? qz : INFINITY)), bhz = uni_f(wave_max(far ? qz : -INFINITY));
-        const float wx = 0.5f * (blx + bhx), wy = 0.5f * (bly + bhy), wz = 0.5f * (blz + bhz);
+        // box of the wave's far queries
+        const float blx = wave_minmax_uniform<false>(far ? qx : INFINITY), bhx = wave_minmax_uniform<true>(far ? qx : -INFINITY);
+        const float bly = wave_minmax_uniform<false>(far ? qy : INFINITY), bhy = wave_minmax_uniform<true>(far ? qy : -INFINITY);
+        const float blz = wave_minmax_uniform<false>(far ? qz : INFINITY), bhz = wave_minmax_uniform<true>(far ? qz : -INFINITY);
         const int lane = threadIdx.x & 63;
         auto lane_i = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
         auto lane_f = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
@@ -352,7 +387,7 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
             const float ddz = fmaxf(fmaxf(z0 - bhz, blz - (z0 + size)), 0.f);
             return ddx * ddx + ddy * ddy + ddz * ddz;
         };
-        auto wave_d8max = [&]() { return uni_f(wave_max(far ? d8() : 0.f)); };
+        auto wave_d8max = [&]() { return wave_minmax_uniform<true>(far ? d8() : 0.f); };
         // Candidates [b, e) (uniform) against every far lane's top-8: the 64 lanes fetch 64 consecutive points with ONE load
         // (1 KB, coalesced), then point j is broadcast from lane j's registers (v_readlane) - one memory round trip per 64
         // candidates (scalar loads, 4 points per round trip, left the wave waiting ~400 cycles per candidate).
@@ -405,43 +440,38 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
             }
             if (__ballot(pend != kNoKey) != 0ull) flush();
         };
-        // A 4 x 4 x 4 group of boxes is looked at by the 64 lanes together, lane = box: lane bits (z, y, x) count from the side
-        // of the group that faces the wave's queries, so ascending lane order opens the nearest boxes first (the 8th keys are
-        // tight after the first non-empty one and the box tests close everything behind).
-        // One coarse cell: lane = fine cell; its point range arrives with two loads per wave (one round trip, where a loop over
-        // the cells waited for 64 dependent loads), the wave-box bound drops most cells in parallel, the rest are tested exactly.
-        auto visit_coarse = [&](int X, int Y, int Z) {
-            const int fx0 = X * kCoarse, fx1 = min(fx0 + kCoarse, G), fy0 = Y * kCoarse, fy1 = min(fy0 + kCoarse, G),
-                      fz0 = Z * kCoarse, fz1 = min(fz0 + kCoarse, G);
-            const bool ux = wx < g.ox + 0.5f * (float)(fx0 + fx1) * g.cs, uy = wy < g.oy + 0.5f * (float)(fy0 + fy1) * g.cs,
-                       uz = wz < g.oz + 0.5f * (float)(fz0 + fz1) * g.cs;
-            auto cell_of = [&](int l, int& x, int& y, int& z) {
-                const int kx = l & 3, ky = (l >> 2) & 3, kz = l >> 4;
-                x = ux ? fx0 + kx : fx1 - 1 - kx; y = uy ? fy0 + ky : fy1 - 1 - ky; z = uz ? fz0 + kz : fz1 - 1 - kz;
-                return x >= fx0 && x < fx1 && y >= fy0 && y < fy1 && z >= fz0 && z < fz1;
-            };
-            int x, y, z, cb = 0, ce = 0;
-            if (cell_of(lane, x, y, z)) {
+        // A 4 x 4 x 4 group of boxes is looked at by the 64 lanes together, lane = box: its count / point range arrives with
+        // one or two loads per WAVE (one round trip, where a loop over the boxes waited for 64 dependent loads), its distance
+        // to the box of the wave's queries is a lower bound for every lane. Boxes are opened BEST FIRST: the nearest one that
+        // can still matter to the lane with the largest 8th distance, then the bounds are looked at again - after the first
+        // non-empty box of a surface wave the 8th distances are a fraction of a cell and nearly everything else drops out in
+        // that parallel test; what survives it is tested against every lane's own query before it is opened.
+        auto best_first = [&](bool cand, float bd2, auto&& open) {
+            const float md = 0.999f * sqrtf(bd2), mdsq = md * md;
+            while (true) {
+                const float d8max = wave_d8max();
+                const bool alive = cand && !(d8max < mdsq);
+                if (__ballot(alive) == 0ull) break;
+                const float v = alive ? bd2 : INFINITY;
+                const float mn = wave_minmax_uniform<false>(v);
+                const int pick = __ffsll((long long)__ballot(alive && v == mn)) - 1;
+                cand = cand && lane != pick;
+                open(pick);
+            }
+        };
+        auto visit_coarse = [&](int X, int Y, int Z) {                        // lane = fine cell of the coarse cell
+            const int fx0 = X * kCoarse, fy0 = Y * kCoarse, fz0 = Z * kCoarse;
+            const int x = fx0 + (lane & 3), y = fy0 + ((lane >> 2) & 3), z = fz0 + (lane >> 4);
+            int cb = 0, ce = 0;
+            if (x < G && y < G && z < G) {
                 const long at = ((long)z * G + y) * G + x;
                 cb = cell_start[at]; ce = cell_start[at + 1];
             }
-            const float d8max = wave_d8max();                                 // (all lanes: a cross-lane reduction)
-            bool cand = ce > cb;
-            if (cand) {
-                const float md = 0.999f * sqrtf(wave_box_d2(g.ox + (float)x * g.cs, g.oy + (float)y * g.cs, g.oz + (float)z * g.cs, g.cs));
-                cand = !(d8max < md * md);
-            }
-            unsigned long long m = __ballot(cand);
-            while (m != 0ull) {
-                const int bit = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                int ux_, uy_, uz_;
-                cell_of(bit, ux_, uy_, uz_);
-                const float ex = axis_d(g.ox + (float)ux_ * g.cs, g.cs, qx), ey = axis_d(g.oy + (float)uy_ * g.cs, g.cs, qy),
-                            ez = axis_d(g.oz + (float)uz_ * g.cs, g.cs, qz);
-                if (!any_needs(ex * ex + ey * ey + ez * ez)) continue;
-                scan_uniform(lane_i(cb, bit), lane_i(ce, bit));
-            }
+            best_first(ce > cb, wave_box_d2(g.ox + (float)x * g.cs, g.oy + (float)y * g.cs, g.oz + (float)z * g.cs, g.cs), [&](int pick) {
+                const float ex = axis_d(g.ox + (float)(fx0 + (pick & 3)) * g.cs, g.cs, qx), ey = axis_d(g.oy + (float)(fy0 + ((pick >> 2) & 3)) * g.cs, g.cs, qy),
+                            ez = axis_d(g.oz + (float)(fz0 + (pick >> 4)) * g.cs, g.cs, qz);
+                if (any_needs(ex * ex + ey * ey + ez * ez)) scan_uniform(lane_i(cb, pick), lane_i(ce, pick));
+            });
         };
         auto box_d2 = [&](float x0, float y0, float z0, float size) {      // squared distance from the lane's query to an axis-aligned cube
             const float ddx = axis_d(x0, size, qx), ddy = axis_d(y0, size, qy), ddz = axis_d(z0, size, qz);
@@ -450,31 +480,13 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
         auto visit_super = [&](int S) {                                       // lane = coarse cell of the block
             const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
             if (!any_needs(box_d2(g.ox + (float)SX * scs, g.oy + (float)SY * scs, g.oz + (float)SZ * scs, scs))) return;
-            const int X0 = SX * kSuper, X1 = min(X0 + kSuper, Gc), Y0 = SY * kSuper, Y1 = min(Y0 + kSuper, Gc),
-                      Z0 = SZ * kSuper, Z1 = min(Z0 + kSuper, Gc);
-            const bool ux = wx < g.ox + 0.5f * (float)(X0 + X1) * ccs, uy = wy < g.oy + 0.5f * (float)(Y0 + Y1) * ccs,
-                       uz = wz < g.oz + 0.5f * (float)(Z0 + Z1) * ccs;
-            auto cell_of = [&](int l, int& Xc, int& Yc, int& Zc) {
-                const int kx = l & 3, ky = (l >> 2) & 3, kz = l >> 4;
-                Xc = ux ? X0 + kx : X1 - 1 - kx; Yc = uy ? Y0 + ky : Y1 - 1 - ky; Zc = uz ? Z0 + kz : Z1 - 1 - kz;
-                return Xc >= X0 && Xc < X1 && Yc >= Y0 && Yc < Y1 && Zc >= Z0 && Zc < Z1;
-            };
-            int Xc, Yc, Zc;
-            const float d8max = wave_d8max();                                 // (all lanes: a cross-lane reduction)
-            bool cand = cell_of(lane, Xc, Yc, Zc) && coarse_cnt[((long)Zc * Gc + Yc) * Gc + Xc] != 0;
-            if (cand) {
-                const float md = 0.999f * sqrtf(wave_box_d2(g.ox + (float)Xc * ccs, g.oy + (float)Yc * ccs, g.oz + (float)Zc * ccs, ccs));
-                cand = !(d8max < md * md);
-            }
-            unsigned long long m = __ballot(cand);
-            while (m != 0ull) {
-                const int bit = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                int Xu, Yu, Zu;
-                cell_of(bit, Xu, Yu, Zu);
-                if (!any_needs(box_d2(g.ox + (float)Xu * ccs, g.oy + (float)Yu * ccs, g.oz + (float)Zu * ccs, ccs))) continue;
-                visit_coarse(Xu, Yu, Zu);
-            }
+            const int X0 = SX * kSuper, Y0 = SY * kSuper, Z0 = SZ * kSuper;
+            const int Xc = X0 + (lane & 3), Yc = Y0 + ((lane >> 2) & 3), Zc = Z0 + (lane >> 4);
+            const bool cand = Xc < Gc && Yc < Gc && Zc < Gc && coarse_cnt[((long)Zc * Gc + Yc) * Gc + Xc] != 0;
+            best_first(cand, wave_box_d2(g.ox + (float)Xc * ccs, g.oy + (float)Yc * ccs, g.oz + (float)Zc * ccs, ccs), [&](int pick) {
+                const int Xu = X0 + (pick & 3), Yu = Y0 + ((pick >> 2) & 3), Zu = Z0 + (pick >> 4);
+                if (any_needs(box_d2(g.ox + (float)Xu * ccs, g.oy + (float)Yu * ccs, g.oz + (float)Zu * ccs, ccs))) visit_coarse(Xu, Yu, Zu);
+            });
         };
         auto box_box_d2 = [&](int S) {
             const int SX = S % Gs, SY = (S / Gs) % Gs, SZ = S / (Gs * Gs);
@@ -489,14 +501,14 @@ __global__ __launch_bounds__(256) void knn8_grid_kernel(const float* __restrict_
             const float d2 = box_box_d2(S);
             if (d2 < best_d2 || (d2 == best_d2 && S < best)) { best_d2 = d2; best = S; }
         }
-        const float wmin = wave_min(best_d2);
+        const float wmin = wave_minmax_uniform<false>(best_d2);
         const unsigned long long at = __ballot(best_d2 == wmin && best != 0x7fffffff);
         int seed = -1;
         if (at != 0ull) seed = __builtin_amdgcn_readfirstlane(__shfl(best, __ffsll((long long)at) - 1, 64));
         if (seed >= 0) visit_super(seed);
         // 2. every other block that can still hold a point nearer than the worst lane's 8th
         for (int base = 0; base < nS; base += 64) {
-            const float d8max = wave_max(far ? d8() : 0.f);                  // (refreshed per batch: the lanes' bounds only shrink)
+            const float d8max = wave_d8max();                                 // (refreshed per batch: the lanes' bounds only shrink)
             const int S = base + lane;
             bool cand = S < nS && S != seed && super_cnt[S] != 0;
             if (cand) {
@@ -635,8 +647,8 @@ extern "C" int nerfail_knn8_grid_build(const float* points, int64_t n_points, vo
 static unsigned long long* g_knn_stats = nullptr;
 extern "C" int nerfail_knn8_grid_stats(unsigned long long* stats) { g_knn_stats = stats; return NERFAIL_OK; }
 
-extern "C" int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_points, float* dist, float* idx_f32,
-                                        int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream) {
+static int grid_search(const float* queries, int64_t n_queries, int view_h, int view_w, int64_t n_points, float* dist, float* idx_f32,
+                       int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream) {
     NF_REQUIRE(n_queries >= 0, "n_queries is negative");
     NF_REQUIRE(n_points >= NERFAIL_KNN && n_points < (1 << 24), "bad n_points");
     if (n_queries == 0) return NERFAIL_OK;
@@ -645,11 +657,25 @@ extern "C" int nerfail_knn8_grid_search(const float* queries, int64_t n_queries,
     NF_REQUIRE(workspace != nullptr && workspace_bytes >= nerfail_knn8_grid_workspace_bytes(n_points),
                "workspace too small (nerfail_knn8_grid_workspace_bytes)");
     const GridWs w = carve(const_cast<void*>(workspace), n_points);
-    knn8_grid_kernel<<<dim3((unsigned)((n_queries + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
-        queries, n_queries, w.gp, w.sorted, w.cell_start, w.coarse_cnt, w.super_cnt, dist, idx_f32, idx_i32,
+    const long waves = view_w > 0 ? (long)((view_w + 7) / 8) * ((view_h + 7) / 8) : (n_queries + 63) / 64;
+    NF_REQUIRE(waves < (1L << 31), "too many queries for one launch");
+    knn8_grid_kernel<<<dim3((unsigned)waves), dim3(64), 0, as_stream(stream)>>>(
+        queries, n_queries, view_h, view_w, w.gp, w.sorted, w.cell_start, w.coarse_cnt, w.super_cnt, dist, idx_f32, idx_i32,
         g_knn_stats);
     NF_LAUNCHED("knn8_grid_kernel");
     return NERFAIL_OK;
+}
+
+extern "C" int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_points, float* dist, float* idx_f32,
+                                        int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream) {
+    return grid_search(queries, n_queries, 0, 0, n_points, dist, idx_f32, idx_i32, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nerfail_knn8_grid_search_view(const float* queries, int height, int width, int64_t n_points, float* dist,
+                                             float* idx_f32, int32_t* idx_i32, const void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+    NF_REQUIRE(height > 0 && width > 0, "bad view size");
+    return grid_search(queries, (int64_t)height * width, height, width, n_points, dist, idx_f32, idx_i32, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nerfail_knn8_grid(const float* queries, int64_t n_queries, const float* points, int64_t n_points, float* dist,

@@ -132,6 +132,21 @@ def test_knn_far_queries_on_view_geometry():
         assert 0.2 < far.mean() < 0.8                                # the far-query path really ran (0.39 and 0.26 here)
 
 
+def test_knn_view_tiles_cover_odd_sizes_and_equal_the_flat_search():
+    """nerfail_knn8_grid_search_view (a wave = an 8 x 8 pixel tile) on views whose sides are not multiples of 8 - edge tiles
+    with repeated lanes - equals the flat search and brute force on the same points, bit for bit, every pixel written."""
+    from nerfail_amd.create_index_and_dist import knn8
+    for H, W in ((37, 53), (8, 8), (9, 130)):
+        S = np.stack([synth.sphere_view_points(64, 64, th) for th in (-120., 0., 120.)]).reshape(-1, 3)
+        Q = synth.sphere_view_points(max(H, W), max(H, W), 45.)[:H, :W].copy()
+        dv, iv = knn8(T(Q), T(S), want_int=True, method='grid')                      # [H,W,3] -> the tiled entry point
+        df, i_f = knn8(T(Q.reshape(-1, 3)), T(S), want_int=True, method='grid')      # flat: 64 consecutive queries per wave
+        db, ib = knn8(T(Q.reshape(-1, 3)), T(S), want_int=True, method='brute')
+        assert dv.shape == (H, W, 8)
+        assert torch_equal(dv.reshape(-1, 8), df) and torch_equal(iv.reshape(-1, 8), i_f), (H, W)
+        assert torch_equal(df, db) and torch_equal(i_f, ib), (H, W)
+
+
 def test_knn_full_size_view_geometry_grid_equals_brute_force():
     """BASELINE-size map build on the geometry of a real view: all 640 000 queries of an 800 x 800 view (31 % of them
     background pixels on the near plane) against the 1.92 M points of 3 base views - the grid search (near path + coarse

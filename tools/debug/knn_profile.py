@@ -14,8 +14,8 @@ S = torch.from_numpy(np.stack([synth.sphere_view_points(H, W, th) for th in (-12
 Q = torch.from_numpy(synth.sphere_view_points(H, W, 45.)).to(dev)
 lib = _lib.load()
 index_and_dist(Q, S)
-NW = (H * W + 63) // 64
-stats = torch.zeros((16 + 7 * NW,), dtype=torch.int64, device=dev)
+NW = (H // 8) * (W // 8)
+stats = torch.zeros((16 + 9 * NW,), dtype=torch.int64, device=dev)
 lib.nerfail_knn8_grid_stats(_lib.dev(stats))
 index_and_dist(Q, S)
 torch.cuda.synchronize()
@@ -34,7 +34,7 @@ print('per far wave us: median %.0f  p90 %.0f  p99 %.0f  max %.0f;  points: medi
       (np.median(t[m]), np.percentile(t[m], 90), np.percentile(t[m], 99), t[m].max(), np.median(pts[m]), np.percentile(pts[m], 99), pts[m].max()))
 order = np.argsort(-t)[:12]
 for w in order:
-    print('  wave %5d (row %3d, col %3d..)  far lanes %2d  points %7d  %.0f us' % (w, (w * 64) // W, (w * 64) % W, nfar[w], pts[w], t[w]))
+    print('  wave %5d (row %3d, col %3d..)  far lanes %2d  points %7d  %.0f us' % (w, (w // (W // 8)) * 8, (w % (W // 8)) * 8, nfar[w], pts[w], t[w]))
 print('sum of far-wave time %.1f ms-waves; by far-lane count: ' % (t[m].sum() / 1e3) +
       ', '.join('%d-%d lanes: %d waves %.0f us avg' % (lo, hi, ((nfar >= lo) & (nfar <= hi)).sum(), t[(nfar >= lo) & (nfar <= hi)].mean())
                 for lo, hi in ((1, 8), (9, 32), (33, 63), (64, 64)) if ((nfar >= lo) & (nfar <= hi)).any()))
@@ -62,7 +62,7 @@ print('waves WITHOUT far lanes: %d; us: median %.0f p90 %.0f p99 %.0f max %.0f; 
       % (nm.sum(), np.median(t[nm]), np.percentile(t[nm], 90), np.percentile(t[nm], 99), t[nm].max(), t[nm].sum() / 1e3,
          np.median(ex[nm]) / 64, np.percentile(ex[nm], 99) / 64, ex[nm].max() / 64))
 for w in np.argsort(-np.where(nm, t, 0))[:8]:
-    print('  wave %5d (row %3d, col %3d..)  candidates per lane %7.0f  %.0f us' % (w, (w * 64) // W, (w * 64) % W, ex[w] / 64, t[w]))
+    print('  wave %5d (row %3d, col %3d..)  candidates per lane %7.0f  %.0f us' % (w, (w // (W // 8)) * 8, (w % (W // 8)) * 8, ex[w] / 64, t[w]))
 allst, allen = (t0 - t0.min()) / 100.0, (t0 - t0.min()) / 100.0 + t
 for mid in (125., 625., 1125., 1625., 2375., 3125.):
     fl = (allst <= mid) & (allen > mid)
@@ -71,4 +71,16 @@ sh = np.array(v[16 + 6 * NW:16 + 7 * NW], dtype=np.float64) / 100.0
 print('shell phase per wave us: all waves median %.0f p90 %.0f p99 %.0f max %.0f, sum %.1f ms-waves; far waves: median %.0f p99 %.0f sum %.1f ms-waves'
       % (np.median(sh), np.percentile(sh, 90), np.percentile(sh, 99), sh.max(), sh.sum() / 1e3, np.median(sh[m]), np.percentile(sh[m], 99), sh[m].sum() / 1e3))
 for w in np.argsort(-sh)[:8]:
-    print('  wave %5d (row %3d, col %3d..)  far lanes %2d  candidates per lane %7.0f  shell phase %.0f us of %.0f' % (w, (w * 64) // W, (w * 64) % W, nfar[w], ex[w] / 64, sh[w], t[w]))
+    print('  wave %5d (row %3d, col %3d..)  far lanes %2d  candidates per lane %7.0f  shell phase %.0f us of %.0f' % (w, (w // (W // 8)) * 8, (w % (W // 8)) * 8, nfar[w], ex[w] / 64, sh[w], t[w]))
+c7 = np.array(v[16 + 7 * NW:16 + 8 * NW], dtype=np.int64)
+c8 = np.array(v[16 + 8 * NW:16 + 9 * NW], dtype=np.int64)
+cells, coarse, blocks, flushes, scan_us = c7 & 0xfffff, (c7 >> 20) & 0xfffff, c7 >> 40, c8 & 0xffffff, (c8 >> 24) / 100.0
+print('slowest waves in detail:')
+for w in np.argsort(-t)[:10]:
+    print('  wave %5d (row %3d, col %3d): %5.0f us, %5.0f in scans; points %6d in %4d cells (%3d coarse, %2d blocks), %4d flushes; started at %.0f us'
+          % (w, (w // (W // 8)) * 8, (w % (W // 8)) * 8, t[w], scan_us[w], pts[w], cells[w], coarse[w], blocks[w], flushes[w], allst[w]))
+k = np.argsort(t)[len(t) // 2 - 3:len(t) // 2 + 3]
+print('median waves:')
+for w in k:
+    print('  wave %5d (row %3d, col %3d): %5.0f us, %5.0f in scans; points %6d in %4d cells (%3d coarse, %2d blocks), %4d flushes; started at %.0f us'
+          % (w, (w // (W // 8)) * 8, (w % (W // 8)) * 8, t[w], scan_us[w], pts[w], cells[w], coarse[w], blocks[w], flushes[w], allst[w]))

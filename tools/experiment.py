@@ -111,20 +111,20 @@ EXPERIMENTS = {
     # points 2.0 / 1.0 ms against 1.3 ms - no clear winner, the search is latency bound)
     # K8 far search: wave-level counters -> stats[2..9] (tools/debug/knn_profile.py)
     'knn_profile': ('knn_grid.hip', [
-        ('    const long qi = valid ? qi_raw : nq - 1;\n', '    const long qi = valid ? qi_raw : nq - 1;\n    const unsigned long long pf_start = wall_clock64();\n'),
+        ('    bool valid;\n    long qi;\n', '    bool valid;\n    long qi;\n    const unsigned long long pf_start = wall_clock64();\n'),
         ('    const bool far = !done;\n', '    const bool far = !done;\n    unsigned long long pf_pts = 0, pf_flush = 0, pf_cells = 0, pf_coarse = 0, pf_super = 0, pf_scan_clk = 0, pf_t0 = wall_clock64();\n'),
         ('            if (far) examined += (unsigned)(e - b);\n            for (int p0 = b; p0 < e; p0 += 64) {',
          '            if (far) examined += (unsigned)(e - b);\n            pf_pts += (unsigned)(e - b); pf_cells += 1; const unsigned long long c0 = wall_clock64();\n            for (int p0 = b; p0 < e; p0 += 64) {'),
         ('                            flush();\n', '                            pf_flush += 1;\n                            flush();\n'),
         ('            if (__ballot(pend != kNoKey) != 0ull) flush();\n', '            if (__ballot(pend != kNoKey) != 0ull) flush();\n            pf_scan_clk += wall_clock64() - c0;\n'),
-        ('        auto visit_coarse = [&](int X, int Y, int Z) {\n', '        auto visit_coarse = [&](int X, int Y, int Z) {\n            pf_coarse += 1;\n'),
+        ('            const int fx0 = X * kCoarse, fy0 = Y * kCoarse, fz0 = Z * kCoarse;\n', '            const int fx0 = X * kCoarse, fy0 = Y * kCoarse, fz0 = Z * kCoarse;\n            pf_coarse += 1;\n'),
         ('        auto visit_super = [&](int S) {                                       // lane = coarse cell of the block\n',
          '        auto visit_super = [&](int S) {                                       // lane = coarse cell of the block\n            pf_super += 1;\n'),
         ('    if (stats != nullptr) {             // [0] candidates examined',
          '    const unsigned long long pf_far = __ballot(far);\n    unsigned long long pf_ex = examined;\n    for (int o = 32; o > 0; o >>= 1) pf_ex += __shfl_xor(pf_ex, o, 64);\n    if (stats != nullptr && (threadIdx.x & 63) == 0) {\n'
          '        atomicAdd(stats + 2, pf_pts); atomicAdd(stats + 3, pf_flush); atomicAdd(stats + 4, pf_cells); atomicAdd(stats + 5, pf_coarse);\n'
          '        atomicAdd(stats + 6, pf_super); atomicAdd(stats + 7, pf_scan_clk); atomicAdd(stats + 8, (unsigned long long)(wall_clock64() - pf_t0));\n'
-         '        atomicAdd(stats + 9, pf_far != 0ull ? 1ull : 0ull);\n        const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (nq + 63) >> 6;\n        stats[16 + gw] = (unsigned long long)(wall_clock64() - pf_start); stats[16 + nw + gw] = pf_pts; stats[16 + 2 * nw + gw] = __popcll(pf_far); stats[16 + 3 * nw + gw] = pf_start; stats[16 + 6 * nw + gw] = pf_t0 - pf_start; stats[16 + 5 * nw + gw] = pf_ex; stats[16 + 4 * nw + gw] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);\n    }\n'
+         '        atomicAdd(stats + 9, pf_far != 0ull ? 1ull : 0ull);\n        const long gw = blockIdx.x, nw = gridDim.x;\n        stats[16 + gw] = (unsigned long long)(wall_clock64() - pf_start); stats[16 + nw + gw] = pf_pts; stats[16 + 2 * nw + gw] = __popcll(pf_far); stats[16 + 3 * nw + gw] = pf_start; stats[16 + 6 * nw + gw] = pf_t0 - pf_start; stats[16 + 5 * nw + gw] = pf_ex; stats[16 + 7 * nw + gw] = pf_cells | (pf_coarse << 20) | (pf_super << 40); stats[16 + 8 * nw + gw] = pf_flush | (pf_scan_clk << 24); stats[16 + 4 * nw + gw] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);\n    }\n'
          '    if (stats != nullptr) {             // [0] candidates examined')], []),
     'knn_g15': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(1.5 * cbrt((double)n));')], []),
     'knn_g20': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(2.0 * cbrt((double)n));')], []),
