@@ -406,8 +406,9 @@ def knn_bench(dev, reps=2):
                      'brute_force_equivalent_pairs_per_sec': float(H * W) * float(3 * H * W) / dt,
                      'roofline': {'bound': 'valu', 'achieved': cand / dt / 1e12, 'peak': peak_evals / 1e12,
                                   'unit': '1e12 distance evaluations/s (8 non-FMA flops each)', 'frac': cand / dt / peak_evals, 'traffic': None,
-                                  'note': 'latency bound: the evaluations are fed by dependent cell-range and point loads; '
-                                          'compulsory HBM traffic is 71.7 MB per view (%.1f GB/s at this rate)' % (71.7e6 / dt / 1e9)}}
+                                  'note': 'a wave searches for its 64 queries together (8 x 8 pixel tile): every lane measures every candidate '
+                                          'the wave opens, 64x the per-query count in lane-evaluations; bounded by instruction issue and by the '
+                                          'slowest tiles (DESIGN.md K8); compulsory HBM traffic is 71.7 MB per view (%.1f GB/s at this rate)' % (71.7e6 / dt / 1e9)}}
     out.update(out['shell_points'])                          # round-1 keys keep their meaning (shell points)
     return out
 

@@ -243,8 +243,9 @@ int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_
 int nerfail_knn8_grid_search_view(const float* queries, int height, int width, int64_t n_points, float* dist, float* idx_f32,
                                   int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream);
 /* Work counters of the grid search (measurement aid, off by default): while `stats` (two device uint64, zeroed by the caller)
- * is set, every search adds [0] the candidate points it computed a distance to and [1] the queries that needed the far
- * search. NULL switches the counters off again. Process-wide, not stream-ordered with other threads' searches. */
+ * is set, every search adds [0] the distances it computed (summed over queries) and [1] the queries answered by the
+ * wave-cooperative search (all of a coherent wave's; the leftovers of the per-lane shell walk otherwise). NULL switches the
+ * counters off again. Process-wide, not stream-ordered with other threads' searches. */
 int nerfail_knn8_grid_stats(unsigned long long* stats);
 
 /* ------------------------------------------------------------------ gauss path (K9-K12) --- */

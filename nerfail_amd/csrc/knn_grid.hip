@@ -4,22 +4,18 @@
 //   build:  bounding box of the point set -> G^3 cells (G ~ M^(1/3)) -> cell id per point -> stable radix sort of
 //           (cell, point index) pairs (rocPRIM via hipCUB) -> points gathered into cell order as float4 (x, y, z,
 //           original index) + cell_start[G^3 + 1] by binary search.
-//   query:  one thread per query; visit the cells of Chebyshev shell R = 0, 1, 2, ... around the query's cell,
-//           keeping the 8 smallest keys (d2, index) in registers (d2 = ((dx*dx + dy*dy) + dz*dz), float32, no FMA,
-//           exactly the brute-force arithmetic; lexicographic insertion because cells are not visited in index order).
-//           After shell R every unvisited point lies outside the (2R+1)^3 block, i.e. at least `bound` away, where
-//           bound = distance from the query to the nearest block face that still has cells behind it. The search
-//           stops once the current 8th key satisfies  d2_8 < (0.999 * bound)^2  (strict, with a safety factor far
-//           above float32 rounding), so no unvisited point can enter the result or tie with it.
-// Far queries. A rendered view is ~60 % background: those pixels' "3-D points" are near-plane points (NC:418-423: argmax of
-// all-zero weights = sample 0) one to two scene units from every point of the set. On the fine grid alone (cell ~0.04)
-// such a query walks ~30 shells of ~8 R^2 cell-range lookups before its 8th distance lies inside the visited block: 60 ms
-// per view instead of 1.3. A query that has not finished after kShellCap fine shells therefore starts again on a COARSE
-// view of the same grid (4x4x4 fine cells per coarse cell, one point count each): it walks coarse shells, skips empty
-// coarse cells (one load) and coarse cells whose box is farther than the current 8th distance (arithmetic only), and
-// scans the 16 x-rows of the others. Same keys, same stopping rule (now on the coarse block): the same bits.
-// Points are image pixels' surface points: on a G ~ 124 grid shell 1 (27 cells, ~10 occupied, ~40 points each)
-// normally finishes the query, ~1000x less work than the 1.92 M-point brute-force scan.
+//   query:  one WAVE per 64 queries (an 8 x 8 pixel tile of a view, or 64 consecutive queries). The key of a candidate is
+//           (d2, index), d2 = ((dx*dx + dy*dy) + dz*dz) in float32 without FMA - exactly the brute-force arithmetic - and
+//           the 8 smallest keys win. A box of the grid (cell, 4^3 cells, 16^3 cells) or a point is skipped only when a lower
+//           bound of its distance, shrunk by the safety factor 0.999 (far above float32 rounding), is STRICTLY above the
+//           current 8th distance: nothing skipped can enter the result or tie with it, whatever the visiting order.
+//           Coherent waves (queries within 6 cells of each other) search together, wave-uniformly (see the kernel);
+//           scattered queries first walk Chebyshev shells R = 0..3 around their own cell, one lane per query, and stop
+//           when the 8th distance lies inside the visited block; what is left joins the wave search.
+// A rendered view is ~60 % background: those pixels' "3-D points" are near-plane points (NC:418-423: argmax of all-zero
+// weights = sample 0) one to two scene units from every point of the set - tens of cells. The wave search ranks the blocks
+// of 4^3 coarse cells (4^3 cells each) by the distance of their boxes and descends best first; ~1000 distances per query
+// where the brute-force scan computes 1.92 M.
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -346,11 +342,12 @@ __global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__
         // the point index in the low word): unsigned integer order == the lexicographic (d2, index) order of the brute-force
         // kernel, one compare per test, and a sorted insert is 8 compare-exchange steps without branches.
         typedef unsigned long long Key;
-        constexpr Key kNoKey = ~0ull;                                        // (d2 bits 0xffffffff: not a distance)
         Key fk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) fk[k] = ((Key)0x7f800000u << 32) | 0x7fffffffu;
-        Key pend = kNoKey;                                                   // one candidate waiting to be inserted (below)
+        constexpr int kPark = 4;
+        Key pend[kPark];                                                     // candidates waiting to be inserted (below)
+        int n_pend = 0;
         auto d8 = [&]() { return __uint_as_float((unsigned)(fk[7] >> 32)); };
         auto insert_key = [&](Key k) {                                       // fk stays sorted; the largest of the 9 keys drops out
 #pragma unroll
@@ -388,35 +385,66 @@ __global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__
             return ddx * ddx + ddy * ddy + ddz * ddz;
         };
         auto wave_d8max = [&]() { return wave_minmax_uniform<true>(far ? d8() : 0.f); };
-        // Candidates [b, e) (uniform) against every far lane's top-8: the 64 lanes fetch 64 consecutive points with ONE load
-        // (1 KB, coalesced), then point j is broadcast from lane j's registers (v_readlane) - one memory round trip per 64
-        // candidates (scalar loads, 4 points per round trip, left the wave waiting ~400 cycles per candidate).
-        // A candidate that passes a lane's threshold is only PARKED in the lane's one-entry `pend`; the sorted insert runs for
-        // the whole wave at once when some lane needs its slot again (and at the end of the cell). With 64 lanes almost every
-        // candidate improved SOME lane, and the wave paid a masked insert (~40 % of the time of this loop) nearly every
-        // iteration; parked, the wave inserts a few hundred times per search instead of a few thousand. A parked key leaves
-        // the threshold stale (too large) until it is inserted: more candidates pass, none is lost.
+        // A candidate that passes a lane's threshold is only PARKED in one of the lane's kPark slots; the sorted inserts run for
+        // the whole wave at once when some lane needs a fifth slot (and at the end of the cell). With 64 lanes almost every
+        // candidate of the first cells improves SOME lane, and the wave paid a masked 8-step insert nearly every iteration
+        // (a surface tile: ~290 insert rounds for ~1000 candidates); parked, it inserts a few dozen times per
+        // search. Parked keys leave the lane's threshold stale (too large) until they are inserted: more candidates pass,
+        // none is lost.
         auto flush = [&]() {
-            if (pend != kNoKey) insert_key(pend);
-            pend = kNoKey;
+#pragma unroll
+            for (int sl = 0; sl < kPark; ++sl) {
+                if (__ballot(sl < n_pend) == 0ull) break;
+                if (sl < n_pend) insert_key(pend[sl]);
+            }
+            n_pend = 0;
+        };
+        auto park = [&](bool p, Key key) {                                   // p: this lane keeps `key`
+            if (__ballot(p & (n_pend == kPark)) != 0ull) {
+                flush();
+                p = p & (key < fk[7]);
+            }
+            if (p) {
+#pragma unroll
+                for (int sl = 0; sl < kPark; ++sl)
+                    if (n_pend == sl) pend[sl] = key;
+                n_pend += 1;
+            }
         };
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        // Candidates [b, e) (uniform) against every far lane's top-8. The 64 lanes fetch 64 consecutive points with ONE load
+        // (1 KB, coalesced) and each lane first bounds ITS point against the box of the wave's queries - a lower bound of its
+        // distance to every one of them, a fraction of a cell away from the true distances when the wave is a pixel tile:
+        // points that cannot reach the largest 8th distance of the wave drop out here, 64 per instruction. The survivors
+        // (ballot) are broadcast from their lanes' registers (v_readlane), four per trip as two float pairs (v_pk_*
+        // arithmetic, no contraction), filtered by one float compare against the lane's 8th distance (<=: ties are settled
+        // on the packed key); the point index is only fetched for candidates that pass.
         auto scan_uniform = [&](int b, int e) {
-            if (far) examined += (unsigned)(e - b);
             for (int p0 = b; p0 < e; p0 += 64) {
                 const int n = min(64, e - p0);
                 const float4 mine = sorted[min(p0 + lane, e - 1)];
-                // Four candidates per trip, as two float pairs (v_pk_* arithmetic, no contraction), filtered by ONE float compare
-                // each against the lane's 8th distance (<=: ties are settled on the packed key below); the point index is only
-                // fetched for candidates that pass. ~8 vector instructions per candidate where the first form of this loop had 20.
-                for (int j = 0; j < n; j += 4) {
+                const float bx = fmaxf(fmaxf(blx - mine.x, mine.x - bhx), 0.f), by = fmaxf(fmaxf(bly - mine.y, mine.y - bhy), 0.f),
+                            bz = fmaxf(fmaxf(blz - mine.z, mine.z - bhz), 0.f);
+                const float lb = 0.999f * sqrtf(bx * bx + by * by + bz * bz);
+                const float d8max = wave_d8max();                             // (all lanes: a cross-lane reduction)
+                unsigned long long m = __ballot(lane < n && !(d8max < lb * lb));
+                if (far) examined += (unsigned)__popcll(m);
+                while (m != 0ull) {
+                    int l[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ok[u] = m != 0ull;
+                        l[u] = ok[u] ? __ffsll((long long)m) - 1 : l[0];
+                        m &= m - 1ull;                                        // (0 stays 0)
+                    }
                     const float d8f = d8();
                     f32x2 d2p[2];
                     bool any = false;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int l0 = min(j + 2 * h, n - 1), l1 = min(j + 2 * h + 1, n - 1);
+                        const int l0 = l[2 * h], l1 = l[2 * h + 1];
                         const f32x2 px = {lane_f(mine.x, l0), lane_f(mine.x, l1)}, py = {lane_f(mine.y, l0), lane_f(mine.y, l1)},
                                     pz = {lane_f(mine.z, l0), lane_f(mine.z, l1)};
                         const f32x2 dx = qx2 - px, dy = qy2 - py, dz = qz2 - pz;
@@ -426,19 +454,16 @@ __global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__
                     if (__ballot(far & any) == 0ull) continue;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (j + u >= n) break;
-                        const unsigned id = (unsigned)lane_i(__float_as_int(mine.w), j + u);
-                        const Key key = ((Key)__float_as_uint(u & 1 ? d2p[u >> 1].y : d2p[u >> 1].x) << 32) | id;
-                        bool p = far & (key < fk[7]);
-                        if (__ballot(p & (pend != kNoKey)) != 0ull) {
-                            flush();
-                            p = p & (key < fk[7]);
-                        }
-                        if (p) pend = key;
+                        if (!ok[u]) break;
+                        const float d2u = u & 1 ? d2p[u >> 1].y : d2p[u >> 1].x;
+                        if (__ballot(far & (d2u <= d8f)) == 0ull) continue;       // (usually one of the four is the one that passed)
+                        const unsigned id = (unsigned)lane_i(__float_as_int(mine.w), l[u]);
+                        const Key key = ((Key)__float_as_uint(d2u) << 32) | id;
+                        park(far & (key < fk[7]), key);
                     }
                 }
             }
-            if (__ballot(pend != kNoKey) != 0ull) flush();
+            if (__ballot(n_pend != 0) != 0ull) flush();
         };
         // A 4 x 4 x 4 group of boxes is looked at by the 64 lanes together, lane = box: its count / point range arrives with
         // one or two loads per WAVE (one round trip, where a loop over the boxes waited for 64 dependent loads), its distance

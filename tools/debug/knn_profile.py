@@ -26,6 +26,8 @@ print('far waves %d; per far wave: points scanned %.0f, flushes %.0f, cells %.1f
       (v[9], v[2] / nw, v[3] / nw, v[4] / nw, v[5] / nw, v[6] / nw))
 print('clock ticks (100 MHz) per far wave: whole kernel %.0f, inside the point scans %.0f  -> %.1f ns per scanned point'
       % (v[8] / nw, v[7] / nw, v[7] * 10.0 / max(v[2], 1)))
+print('per far wave: %.1f point loads waiting %.1f us in all (%.2f us each); %.0f slow trips (%.0f points survive the box prefilter) taking %.1f us in all (%.2f us each)'
+      % (v[11] / nw, v[10] / nw / 100.0, v[10] / max(v[11], 1) / 100.0, v[12] / nw, v[14] / nw, v[13] / nw / 100.0, v[13] / max(v[12], 1) / 100.0))
 a = np.array(v[16:16 + 5 * NW], dtype=np.float64).reshape(5, NW)
 hw = np.array(v[16 + 4 * NW:16 + 5 * NW], dtype=np.int64)
 t, pts, nfar = a[0] / 100.0, a[1], a[2]          # us
