@@ -78,34 +78,46 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def kernel_source_hashes():
+    """sha256 (16 hex digits) of every file of nerfail_amd/csrc: ties a stored PMC measurement to the kernel sources it was
+    taken from, file by file (a change to the kNN kernel does not invalidate the MLP kernel's counters)."""
+    import hashlib
+    d = os.path.join(ROOT, 'nerfail_amd', 'csrc')
+    return {f: hashlib.sha256(open(os.path.join(d, f), 'rb').read()).hexdigest()[:16]
+            for f in sorted(os.listdir(d)) if f.endswith(('.hip', '.h'))}
+
+
 def kernel_source_hash():
-    """sha256 (16 hex digits) over nerfail_amd/csrc: ties a stored PMC measurement to the kernels it was taken from."""
     import hashlib
     h = hashlib.sha256()
-    d = os.path.join(ROOT, 'nerfail_amd', 'csrc')
-    for f in sorted(os.listdir(d)):
-        if f.endswith(('.hip', '.h')):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), 'rb').read())
+    for f, v in kernel_source_hashes().items():
+        h.update(f.encode())
+        h.update(v.encode())
     return h.hexdigest()[:16]
 
 
+# the translation units (and the headers they include) a profiled kernel is compiled from
+KERNEL_SOURCES = {'nerf_mlp_fwd_lds_kernel': ('mlp_lds.hip', 'mlp_layout.h', 'common.h'),
+                  'gauss_': ('gauss.hip', 'gauss_csr.hip', 'common.h'), 'igsm_': ('gauss.hip', 'common.h'),
+                  'seg_': ('gauss_csr.hip', 'common.h')}
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(kernel_substr, which='avg'):
     """HBM(+Infinity Cache) bytes per launch of a kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 +
-    WRITE_SIZE, MI355X_MICROARCH.md; tools/profile_bench.sh + tools/pmc_summary.py write the file). PMC counters cannot be
+    WRITE_SIZE, MI355X_MICROARCH.md; tools/r03_prof_b.sh + tools/pmc_summary.py write the file). PMC counters cannot be
     read from inside this process, so the number is a stored measurement: it is reported ONLY if the file was taken from
-    the very kernel sources this run uses (csrc hash) - otherwise null, with the reason. which = 'avg' (mean over the
-    profiled command's launches) or 'max' (its largest launch: for kernels that also run at smaller sizes there)."""
+    the very sources this run compiles that kernel from (per-file hashes) - otherwise null, with the reason. which = 'avg'
+    (mean over the profiled command's launches) or 'max' (its largest launch: for kernels that also run at smaller sizes)."""
     try:
         pmc = json.load(open(PMC_FILE))
     except (OSError, ValueError):
         return None, 'no PMC file (%s)' % os.path.basename(PMC_FILE)
-    if pmc.get('csrc_sha16') != kernel_source_hash():
-        return None, 'stale: %s was measured on csrc %s, this run is %s' % (os.path.basename(PMC_FILE), pmc.get('csrc_sha16'),
-                                                                          kernel_source_hash())
+    now, then = kernel_source_hashes(), pmc.get('csrc_files', {})
+    files = next((v for k, v in KERNEL_SOURCES.items() if k in kernel_substr), tuple(now))
+    changed = [f for f in files if now.get(f) != then.get(f)]
+    if changed:
+        return None, 'stale: %s was measured before %s changed' % (os.path.basename(PMC_FILE), ', '.join(changed))
     for name, v in pmc.get('kernels', {}).items():
         if kernel_substr in name:
             f = v['fetch_bytes_per_launch_corrected' if which == 'avg' else 'fetch_bytes_max_launch_corrected']
@@ -113,7 +125,7 @@ def pmc_traffic(kernel_substr, which='avg'):
             if f is None or w is None:
                 return None, 'kernel missing from one of the two counter passes'
             return f + w, {'file': 'profiles/' + os.path.basename(PMC_FILE), 'command': pmc.get('command'),
-                           'csrc_sha16': pmc.get('csrc_sha16'), 'launch': which}
+                           'sources': {x: now[x] for x in files}, 'launch': which}
     return None, 'kernel not in ' + os.path.basename(PMC_FILE)
 
 

@@ -22,11 +22,11 @@ def main():
     fetch, write = read(sys.argv[1], 'FETCH_SIZE'), read(sys.argv[2], 'WRITE_SIZE')
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
     try:                                       # ties the measurement to the kernel sources it was taken from:
-        import bench                           # bench.py reports roofline.traffic only when this hash matches its own
-        sha = bench.kernel_source_hash()
+        import bench                           # bench.py reports a kernel's traffic only while the files it is compiled from still hash the same
+        sha, files = bench.kernel_source_hash(), bench.kernel_source_hashes()
     except Exception:
-        sha = None
-    out = {'command': sys.argv[3] if len(sys.argv) > 3 else '', 'csrc_sha16': sha,
+        sha, files = None, {}
+    out = {'command': sys.argv[3] if len(sys.argv) > 3 else '', 'csrc_sha16': sha, 'csrc_files': files,
            'correction': 'FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), KB -> bytes x1024; WRITE_SIZE KB -> bytes',
            'kernels': {}}
     for k in sorted(set(fetch) | set(write)):
