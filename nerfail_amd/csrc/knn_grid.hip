@@ -137,23 +137,21 @@ __global__ __launch_bounds__(256) void super_count_kernel(const int* __restrict_
     cnt[c] = n;
 }
 
-struct Top8L {
-    float d[8];
-    int i[8];
-};
-
-__device__ __forceinline__ bool key_less(float d2, int idx, float d, int i) { return d2 < d || (d2 == d && idx < i); }
-
-__device__ __forceinline__ void top8_insert_lex(Top8L& t, float d2, int idx) {
+// A query's 8 best candidates are packed 64-bit keys, ascending: float32 bits of d2 (non-negative) in the high word, the point
+// index in the low word - unsigned integer order == the lexicographic (d2, index) order of the brute-force kernel, one compare
+// per test, and a sorted insert is 8 compare-exchange steps without branches.
+typedef unsigned long long Key;
+constexpr Key kWorstKey = ((Key)0x7f800000u << 32) | 0x7fffffffu;       // (d2 = +inf, index = int max)
+__device__ __forceinline__ Key pack_key(float d2, int idx) { return ((Key)__float_as_uint(d2) << 32) | (unsigned)idx; }
+__device__ __forceinline__ float key_d2(Key k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ void insert_key(Key (&fk)[8], Key k) {       // fk stays sorted; the largest of the 9 keys drops out
 #pragma unroll
-    for (int k = 7; k >= 1; --k) {
-        const bool shift = key_less(d2, idx, t.d[k - 1], t.i[k - 1]);
-        const bool here = !shift && key_less(d2, idx, t.d[k], t.i[k]);
-        const float nd = shift ? t.d[k - 1] : (here ? d2 : t.d[k]);
-        const int ni = shift ? t.i[k - 1] : (here ? idx : t.i[k]);
-        t.d[k] = nd; t.i[k] = ni;
+    for (int i = 0; i < 8; ++i) {
+        const bool c = k < fk[i];
+        const Key lo = c ? k : fk[i];
+        k = c ? fk[i] : k;
+        fk[i] = lo;
     }
-    if (key_less(d2, idx, t.d[0], t.i[0])) { t.d[0] = d2; t.i[0] = idx; }
 }
 
 #ifndef NF_KNN_BATCH
@@ -163,7 +161,7 @@ __device__ __forceinline__ void top8_insert_lex(Top8L& t, float d2, int idx) {
 // is examined (clamped index, so the loads are unconditional): the search is latency bound, one dependent 16-byte load
 // per candidate otherwise. The order in which candidates are examined does not matter: the key (d2, index) is total.
 __device__ __forceinline__ void scan_points(const float4* __restrict__ sorted, int b, int e, float qx, float qy, float qz,
-                                            Top8L& top, unsigned& examined) {
+                                            Key (&fk)[8], unsigned& examined) {
     constexpr int U = NF_KNN_BATCH;
     examined += (unsigned)(e - b);
     for (int p = b; p < e; p += U) {
@@ -176,7 +174,8 @@ __device__ __forceinline__ void scan_points(const float4* __restrict__ sorted, i
                 const float dx = __fsub_rn(qx, pt[u].x), dy = __fsub_rn(qy, pt[u].y), dz = __fsub_rn(qz, pt[u].z);
                 const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
                 const int id = __float_as_int(pt[u].w);
-                if (key_less(d2, id, top.d[7], top.i[7])) top8_insert_lex(top, d2, id);
+                const Key key = pack_key(d2, id);
+                if (key < fk[7]) insert_key(fk, key);
             }
         }
     }
@@ -197,9 +196,11 @@ __device__ __forceinline__ float wave_minmax_uniform(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-constexpr int kCoherentCells = 6;     // a wave whose queries span at most this many cells per axis searches as ONE (see below)
+constexpr int kCoherentCells = 6;     // lanes whose queries span at most this many cells per axis search as ONE group (see below)
+constexpr int kGroupPasses = 4;       // groups per wave before the rest goes lane by lane
+constexpr int kMinGroup = 8;
 
-__global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__ queries, long nq, int view_h, int view_w, const Grid* __restrict__ gp,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void knn8_grid_kernel(const float* __restrict__ queries, long nq, int view_h, int view_w, const Grid* __restrict__ gp,
                                                         const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                                         const int* __restrict__ coarse_cnt, const int* __restrict__ super_cnt, float* __restrict__ dist, float* __restrict__ idx_f,
                                                         int* __restrict__ idx_i, unsigned long long* __restrict__ stats) {
@@ -223,108 +224,106 @@ __global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__
     const int G = g.G;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
     const int cx = cell_coord(qx, g.ox, g.inv_cs, G), cy = cell_coord(qy, g.oy, g.inv_cs, G), cz = cell_coord(qz, g.oz, g.inv_cs, G);
-    Top8L top;
+    Key fk[8];                           // this lane's result (the shell walk and the wave search both work on it)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { top.d[k] = INFINITY; top.i[k] = 0x7fffffff; }
+    for (int k = 0; k < 8; ++k) fk[k] = kWorstKey;
     unsigned examined = 0u;             // candidate points this query computed a distance to (reported through `stats`)
 
-    bool done = false;
-    // a query more than kShellCap cells outside the grid cannot finish in the shell phase (its clamped cell's shells stay
-    // farther than that from it): it goes straight to the ranked search (whatever the shells found is discarded there anyway)
-    const float ext = g.cs * (float)G;
-    const float outside = fmaxf(fmaxf(fmaxf(g.ox - qx, qx - (g.ox + ext)), fmaxf(g.oy - qy, qy - (g.oy + ext))),
-                                fmaxf(g.oz - qz, qz - (g.oz + ext)));
-    bool skip_shells = outside > (float)(kShellCap + 1) * g.cs;
-    // The 64 queries of a wave are neighbouring pixels of a view: when they lie within a few cells of each other (they do
-    // except across silhouettes and image rows) the wave searches for all of them TOGETHER (below): one instruction stream,
-    // coalesced loads, shared candidates. Only waves of scattered queries take the per-lane shell walk first.
-    const float wex = wave_minmax_uniform<true>(qx) - wave_minmax_uniform<false>(qx), wey = wave_minmax_uniform<true>(qy) - wave_minmax_uniform<false>(qy),
-                wez = wave_minmax_uniform<true>(qz) - wave_minmax_uniform<false>(qz);
-    const bool coherent = fmaxf(fmaxf(wex, wey), wez) <= (float)kCoherentCells * g.cs;
-    skip_shells = skip_shells || coherent;
     const int Gc = (G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper;
-    if (!skip_shells) {
-        // the 3 x 3 x 3 coarse cells around the query's coarse cell contain every fine cell of shells 0..kShellCap (kShellCap <
-        // kCoarse): if they hold no point (a background pixel's near-plane point in empty space) the shell walk - ~100 dependent
-        // lookups of empty cell ranges - is skipped. 27 independent loads.
-        static_assert(kShellCap < kCoarse, "coarse neighbourhood must cover the shell block");
-        const int CX = cx / kCoarse, CY = cy / kCoarse, CZ = cz / kCoarse;
-        int near = 0;
+    // ---- scattered queries: one lane per query walks the Chebyshev shells R = 0..kShellCap around its own cell (returns
+    // true when the query is finished: `fk` holds its result)
+    auto shell_walk = [&]() -> bool {
+        bool done = false;
+        // a query more than kShellCap cells outside the grid cannot finish in the shell phase (its clamped cell's shells stay
+        // farther than that from it): it goes straight to the ranked search (whatever the shells found is discarded there anyway)
+        const float ext = g.cs * (float)G;
+        const float outside = fmaxf(fmaxf(fmaxf(g.ox - qx, qx - (g.ox + ext)), fmaxf(g.oy - qy, qy - (g.oy + ext))),
+                                    fmaxf(g.oz - qz, qz - (g.oz + ext)));
+        bool skip_shells = outside > (float)(kShellCap + 1) * g.cs;
+        if (!skip_shells) {
+            // the 3 x 3 x 3 coarse cells around the query's coarse cell contain every fine cell of shells 0..kShellCap (kShellCap <
+            // kCoarse): if they hold no point (a background pixel's near-plane point in empty space) the shell walk - ~100 dependent
+            // lookups of empty cell ranges - is skipped. 27 independent loads.
+            static_assert(kShellCap < kCoarse, "coarse neighbourhood must cover the shell block");
+            const int CX = cx / kCoarse, CY = cy / kCoarse, CZ = cz / kCoarse;
+            int near = 0;
 #pragma unroll
-        for (int dz = -1; dz <= 1; ++dz)
+            for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+                for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int X = min(max(CX + dx, 0), Gc - 1), Y = min(max(CY + dy, 0), Gc - 1), Z = min(max(CZ + dz, 0), Gc - 1);
-                    near |= coarse_cnt[((long)Z * Gc + Y) * Gc + X];
-                }
-        skip_shells = near == 0;
-    }
-    // a cell (or a whole x row of cells) whose box lies farther from the query than the current 8th key cannot change the
-    // result (strict, same 0.999 safety factor as the stopping rule): it is not opened. After shell 0 the 8th distance of a
-    // surface query is a fraction of the cell size, so of the 26 cells of shell 1 only the few the query is close to are
-    // scanned - on view geometry (~100 points per surface cell) that is most of the candidates (round 3).
-    auto cannot_improve_shell = [&](float d2box) {
-        const float md = 0.999f * sqrtf(d2box);
-        return top.d[7] < md * md;
-    };
-    for (int R = 0; R < G && R <= kShellCap && !skip_shells; ++R) {
-        const int z0 = max(cz - R, 0), z1 = min(cz + R, G - 1);
-        const int y0 = max(cy - R, 0), y1 = min(cy + R, G - 1);
-        const int x0 = max(cx - R, 0), x1 = min(cx + R, G - 1);
-        for (int z = z0; z <= z1; ++z) {
-            const bool zface = (z == cz - R) || (z == cz + R);
-            const float cz0 = g.oz + (float)z * g.cs;
-            const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
-            for (int y = y0; y <= y1; ++y) {
-                const bool yface = zface || (y == cy - R) || (y == cy + R);
-                const float cy0 = g.oy + (float)y * g.cs;
-                const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
-                const float eyz = ey * ey + ez * ez;
-                if (R > 0 && cannot_improve_shell(eyz)) continue;              // the whole row is too far
-                // on a z / y face of the shell the whole x row belongs to it; otherwise only the two end cells x = cx -+ R do
-                const long row = ((long)z * G + y) * G;
-                if (yface) {
-                    if (R == 0) {
-                        scan_points(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, top, examined);
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int X = min(max(CX + dx, 0), Gc - 1), Y = min(max(CY + dy, 0), Gc - 1), Z = min(max(CZ + dz, 0), Gc - 1);
+                        near |= coarse_cnt[((long)Z * Gc + Y) * Gc + X];
+                    }
+            skip_shells = near == 0;
+        }
+        // a cell (or a whole x row of cells) whose box lies farther from the query than the current 8th key cannot change the
+        // result (strict, same 0.999 safety factor as the stopping rule): it is not opened. After shell 0 the 8th distance of a
+        // surface query is a fraction of the cell size, so of the 26 cells of shell 1 only the few the query is close to are
+        // scanned - on view geometry (~100 points per surface cell) that is most of the candidates (round 3).
+        auto cannot_improve_shell = [&](float d2box) {
+            const float md = 0.999f * sqrtf(d2box);
+            return key_d2(fk[7]) < md * md;
+        };
+        for (int R = 0; R < G && R <= kShellCap && !skip_shells; ++R) {
+            const int z0 = max(cz - R, 0), z1 = min(cz + R, G - 1);
+            const int y0 = max(cy - R, 0), y1 = min(cy + R, G - 1);
+            const int x0 = max(cx - R, 0), x1 = min(cx + R, G - 1);
+            for (int z = z0; z <= z1; ++z) {
+                const bool zface = (z == cz - R) || (z == cz + R);
+                const float cz0 = g.oz + (float)z * g.cs;
+                const float ez = fmaxf(fmaxf(cz0 - qz, qz - (cz0 + g.cs)), 0.f);
+                for (int y = y0; y <= y1; ++y) {
+                    const bool yface = zface || (y == cy - R) || (y == cy + R);
+                    const float cy0 = g.oy + (float)y * g.cs;
+                    const float ey = fmaxf(fmaxf(cy0 - qy, qy - (cy0 + g.cs)), 0.f);
+                    const float eyz = ey * ey + ez * ez;
+                    if (R > 0 && cannot_improve_shell(eyz)) continue;              // the whole row is too far
+                    // on a z / y face of the shell the whole x row belongs to it; otherwise only the two end cells x = cx -+ R do
+                    const long row = ((long)z * G + y) * G;
+                    if (yface) {
+                        if (R == 0) {
+                            scan_points(sorted, cell_start[row + x0], cell_start[row + x1 + 1], qx, qy, qz, fk, examined);
+                        } else {
+                            int b = cell_start[row + x0];
+                            for (int x = x0; x <= x1; ++x) {
+                                const int e = cell_start[row + x + 1];
+                                const float cx0 = g.ox + (float)x * g.cs;
+                                const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
+                                if (e > b && !cannot_improve_shell(ex * ex + eyz)) scan_points(sorted, b, e, qx, qy, qz, fk, examined);
+                                b = e;
+                            }
+                        }
                     } else {
-                        int b = cell_start[row + x0];
-                        for (int x = x0; x <= x1; ++x) {
-                            const int e = cell_start[row + x + 1];
+#pragma unroll
+                        for (int side = 0; side < 2; ++side) {
+                            const int x = side ? cx + R : cx - R;
+                            if (x < 0 || x >= G || (side == 1 && R == 0)) continue;
                             const float cx0 = g.ox + (float)x * g.cs;
                             const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
-                            if (e > b && !cannot_improve_shell(ex * ex + eyz)) scan_points(sorted, b, e, qx, qy, qz, top, examined);
-                            b = e;
+                            if (cannot_improve_shell(ex * ex + eyz)) continue;
+                            scan_points(sorted, cell_start[row + x], cell_start[row + x + 1], qx, qy, qz, fk, examined);
                         }
-                    }
-                } else {
-#pragma unroll
-                    for (int side = 0; side < 2; ++side) {
-                        const int x = side ? cx + R : cx - R;
-                        if (x < 0 || x >= G || (side == 1 && R == 0)) continue;
-                        const float cx0 = g.ox + (float)x * g.cs;
-                        const float ex = fmaxf(fmaxf(cx0 - qx, qx - (cx0 + g.cs)), 0.f);
-                        if (cannot_improve_shell(ex * ex + eyz)) continue;
-                        scan_points(sorted, cell_start[row + x], cell_start[row + x + 1], qx, qy, qz, top, examined);
                     }
                 }
             }
+            // every unvisited point is outside the block [c-R, c+R]^3: lower bound of its distance to the query
+            float bound = INFINITY;
+            if (cx - R > 0) bound = fminf(bound, qx - (g.ox + (float)(cx - R) * g.cs));
+            if (cx + R < G - 1) bound = fminf(bound, (g.ox + (float)(cx + R + 1) * g.cs) - qx);
+            if (cy - R > 0) bound = fminf(bound, qy - (g.oy + (float)(cy - R) * g.cs));
+            if (cy + R < G - 1) bound = fminf(bound, (g.oy + (float)(cy + R + 1) * g.cs) - qy);
+            if (cz - R > 0) bound = fminf(bound, qz - (g.oz + (float)(cz - R) * g.cs));
+            if (cz + R < G - 1) bound = fminf(bound, (g.oz + (float)(cz + R + 1) * g.cs) - qz);
+            if (bound == INFINITY) { done = true; break; }      // the block covers the whole grid
+            if (bound > 0.f) {
+                const float sb = 0.999f * bound;
+                if (key_d2(fk[7]) < sb * sb) { done = true; break; } // strict: nothing unvisited can enter or tie
+            }
         }
-        // every unvisited point is outside the block [c-R, c+R]^3: lower bound of its distance to the query
-        float bound = INFINITY;
-        if (cx - R > 0) bound = fminf(bound, qx - (g.ox + (float)(cx - R) * g.cs));
-        if (cx + R < G - 1) bound = fminf(bound, (g.ox + (float)(cx + R + 1) * g.cs) - qx);
-        if (cy - R > 0) bound = fminf(bound, qy - (g.oy + (float)(cy - R) * g.cs));
-        if (cy + R < G - 1) bound = fminf(bound, (g.oy + (float)(cy + R + 1) * g.cs) - qy);
-        if (cz - R > 0) bound = fminf(bound, qz - (g.oz + (float)(cz - R) * g.cs));
-        if (cz + R < G - 1) bound = fminf(bound, (g.oz + (float)(cz + R + 1) * g.cs) - qz);
-        if (bound == INFINITY) { done = true; break; }      // the block covers the whole grid
-        if (bound > 0.f) {
-            const float sb = 0.999f * bound;
-            if (top.d[7] < sb * sb) { done = true; break; } // strict: nothing unvisited can enter or tie
-        }
-    }
+        return done;
+    };
     // ---- far queries (background pixels' points on the near plane: one to two units from every point, tens of cells): no shell
     // walk - the blocks of kSuper^3 coarse cells are RANKED by the distance of their boxes, a block / coarse cell / fine cell
     // is opened only if its box can still hold a point nearer than the lane's current 8th (strict, same 0.999 safety factor
@@ -336,35 +335,22 @@ __global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__
     // wave's far queries (a lower bound for each of them), the nearest non-empty block seeds every lane's top-8, and only the
     // blocks that can still matter to ANY lane (ballot) are walked - by all lanes together, so the count and cell-range
     // loads are wave-uniform - with the per-lane box tests deciding what each lane actually scans.
-    const bool far = !done;
-    if (__ballot(far) != 0ull) {
-        // The far search keeps a lane's 8 keys as packed 64-bit integers (float32 bits of d2, non-negative, in the high word,
-        // the point index in the low word): unsigned integer order == the lexicographic (d2, index) order of the brute-force
-        // kernel, one compare per test, and a sorted insert is 8 compare-exchange steps without branches.
-        typedef unsigned long long Key;
-        Key fk[8];
+    // ---- the wave search: the lanes of `far` are searched TOGETHER (they lie within a few cells of each other, or are what the
+    // shell walk left over)
+    auto wave_search = [&](const bool far) {
+        if (far) {                                                           // (whatever a shell walk found for these lanes is found again)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) fk[k] = ((Key)0x7f800000u << 32) | 0x7fffffffu;
+            for (int k = 0; k < 8; ++k) fk[k] = kWorstKey;
+        }
+        auto d8 = [&]() { return key_d2(fk[7]); };
         constexpr int kPark = 4;
         Key pend[kPark];                                                     // candidates waiting to be inserted (below)
         int n_pend = 0;
-        auto d8 = [&]() { return __uint_as_float((unsigned)(fk[7] >> 32)); };
-        auto insert_key = [&](Key k) {                                       // fk stays sorted; the largest of the 9 keys drops out
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool c = k < fk[i];
-                const Key lo = c ? k : fk[i];
-                k = c ? fk[i] : k;
-                fk[i] = lo;
-            }
-        };
-        // Round 3, second step: the WHOLE walk is wave-uniform. Blocks, coarse cells, fine cells and candidate points are
-        // visited by the wave in one common order (all indices live in scalar registers: counts, cell ranges and the points
-        // themselves arrive through scalar loads, no vector memory traffic at all); a lane only contributes its own box tests
-        // - "can this box still hold a point nearer than MY 8th?" - and a box is opened when ANY far lane says yes (ballot).
-        // Every far lane then measures every point the wave opens: extra candidates never change an exact result, the lanes'
-        // bounds tighten together, and 64 neighbouring pixels' searches cost one instruction stream instead of 64 divergent
-        // chains of dependent loads (per-lane walk inside the blocks: 6.1 ms of the 6.7 ms view).
+        // The WHOLE walk is wave-uniform. Blocks, coarse cells, fine cells and candidate points are visited by the wave in one
+        // common order; a lane only contributes its own box tests - "can this box still hold a point nearer than MY 8th?" - and
+        // a box is opened when ANY lane of the group says yes (ballot). Every lane of the group then measures every candidate
+        // the wave lets through: extra candidates never change an exact result, the lanes' bounds tighten together, and 64
+        // neighbouring pixels' searches cost one instruction stream instead of 64 divergent chains of dependent loads.
         const float ccs = g.cs * (float)kCoarse, scs = ccs * (float)kSuper;
         auto any_needs = [&](float d2box) {                                  // does any far lane still need a box at this distance?
             const float md = 0.999f * sqrtf(d2box);
@@ -395,7 +381,7 @@ __global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__
 #pragma unroll
             for (int sl = 0; sl < kPark; ++sl) {
                 if (__ballot(sl < n_pend) == 0ull) break;
-                if (sl < n_pend) insert_key(pend[sl]);
+                if (sl < n_pend) insert_key(fk, pend[sl]);
             }
             n_pend = 0;
         };
@@ -547,24 +533,44 @@ __global__ __launch_bounds__(64) void knn8_grid_kernel(const float* __restrict__
                 visit_super(base + bit);
             }
         }
-        if (far) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { top.d[k] = __uint_as_float((unsigned)(fk[k] >> 32)); top.i[k] = (int)(unsigned)fk[k]; }
+    };
+    // The 64 queries of a wave are neighbouring pixels of a view. Up to kGroupPasses times the first unsolved lane names a
+    // group - the unsolved lanes within kCoherentCells / 2 cells of its query - and the wave searches for the whole group at
+    // once: one instruction stream, coalesced loads, shared candidates. A pixel tile is one group; a tile across a silhouette
+    // is two or three (surface / background). Groups of fewer than kMinGroup lanes are not worth a wave-wide search: what is
+    // left then takes the per-lane shell walk, and the wave search once more for the queries that did not finish there.
+    bool pending = true;
+    unsigned long long searched = 0ull;
+    for (int pass = 0; __ballot(pending) != 0ull; ++pass) {
+        bool grp;
+        if (pass < kGroupPasses) {
+            const int sl = __ffsll((long long)__ballot(pending)) - 1;
+            const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), sl)), sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), sl)),
+                        sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), sl));
+            grp = pending && fmaxf(fmaxf(fabsf(qx - sx), fabsf(qy - sy)), fabsf(qz - sz)) <= 0.5f * (float)kCoherentCells * g.cs;
+            if (__popcll(__ballot(grp)) < kMinGroup) { pass = kGroupPasses - 1; continue; }
+        } else {
+            bool done = false;
+            if (pending) done = shell_walk();
+            grp = pending && !done;
+            pending = grp;
         }
+        searched += __popcll(__ballot(valid && grp));
+        if (__ballot(grp) != 0ull) wave_search(grp);
+        pending = pending && !grp;
     }
     if (stats != nullptr) {             // [0] candidates examined, [1] queries that took the far search (one atomic per wave)
         unsigned long long tot = valid ? examined : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-        const unsigned long long nfar = __popcll(__ballot(valid && far));
-        if ((threadIdx.x & 63) == 0) { atomicAdd(stats, tot); atomicAdd(stats + 1, nfar); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(stats, tot); atomicAdd(stats + 1, searched); }
     }
     if (!valid) return;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        dist[8 * qi + k] = sqrt_rn(top.d[k]);
-        if (idx_f != nullptr) idx_f[8 * qi + k] = (float)top.i[k];
-        if (idx_i != nullptr) idx_i[8 * qi + k] = top.i[k];
+        dist[8 * qi + k] = sqrt_rn(key_d2(fk[k]));
+        if (idx_f != nullptr) idx_f[8 * qi + k] = (float)(int)(unsigned)fk[k];
+        if (idx_i != nullptr) idx_i[8 * qi + k] = (int)(unsigned)fk[k];
     }
 }
 

@@ -112,7 +112,9 @@ EXPERIMENTS = {
     # K8 far search: wave-level counters -> stats[2..9] (tools/debug/knn_profile.py)
     'knn_profile': ('knn_grid.hip', [
         ('    bool valid;\n    long qi;\n', '    bool valid;\n    long qi;\n    const unsigned long long pf_start = wall_clock64();\n'),
-        ('    const bool far = !done;\n', '    const bool far = !done;\n    unsigned long long pf_pts = 0, pf_flush = 0, pf_cells = 0, pf_coarse = 0, pf_super = 0, pf_scan_clk = 0, pf_load_clk = 0, pf_loads = 0, pf_slow = 0, pf_slow_clk = 0, pf_eval = 0, pf_t0 = wall_clock64();\n'),
+        ('            if (pending) done = shell_walk();\n', '            const unsigned long long psh = wall_clock64();\n            if (pending) done = shell_walk();\n            pf_shell += wall_clock64() - psh;\n'),
+        ('    auto wave_search = [&](const bool far) {\n', '    unsigned long long pf_far = 0;\n    auto wave_search = [&](const bool far) {\n        pf_far |= __ballot(far);\n'),
+        ('    const int Gc = (G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper;\n    // ---- scattered', '    unsigned long long pf_pts = 0, pf_flush = 0, pf_cells = 0, pf_coarse = 0, pf_super = 0, pf_scan_clk = 0, pf_load_clk = 0, pf_loads = 0, pf_slow = 0, pf_slow_clk = 0, pf_eval = 0, pf_shell = 0, pf_t0 = wall_clock64();\n    const int Gc = (G + kCoarse - 1) / kCoarse, Gs = (Gc + kSuper - 1) / kSuper;\n    // ---- scattered'),
         ('        auto scan_uniform = [&](int b, int e) {\n            for (int p0 = b; p0 < e; p0 += 64) {',
          '        auto scan_uniform = [&](int b, int e) {\n            pf_pts += (unsigned)(e - b); pf_cells += 1; const unsigned long long c0 = wall_clock64();\n            for (int p0 = b; p0 < e; p0 += 64) {'),
         ('                if (far) examined += (unsigned)__popcll(m);\n', '                if (far) examined += (unsigned)__popcll(m);\n                pf_eval += (unsigned)__popcll(m);\n'),
@@ -128,10 +130,10 @@ EXPERIMENTS = {
         ('        auto visit_super = [&](int S) {                                       // lane = coarse cell of the block\n',
          '        auto visit_super = [&](int S) {                                       // lane = coarse cell of the block\n            pf_super += 1;\n'),
         ('    if (stats != nullptr) {             // [0] candidates examined',
-         '    const unsigned long long pf_far = __ballot(far);\n    unsigned long long pf_ex = examined;\n    for (int o = 32; o > 0; o >>= 1) pf_ex += __shfl_xor(pf_ex, o, 64);\n    if (stats != nullptr && (threadIdx.x & 63) == 0) {\n'
+         '    unsigned long long pf_ex = examined;\n    for (int o = 32; o > 0; o >>= 1) pf_ex += __shfl_xor(pf_ex, o, 64);\n    if (stats != nullptr && (threadIdx.x & 63) == 0) {\n'
          '        atomicAdd(stats + 2, pf_pts); atomicAdd(stats + 3, pf_flush); atomicAdd(stats + 4, pf_cells); atomicAdd(stats + 5, pf_coarse);\n'
          '        atomicAdd(stats + 6, pf_super); atomicAdd(stats + 7, pf_scan_clk); atomicAdd(stats + 8, (unsigned long long)(wall_clock64() - pf_t0));\n'
-         '        atomicAdd(stats + 9, pf_far != 0ull ? 1ull : 0ull); atomicAdd(stats + 10, pf_load_clk); atomicAdd(stats + 11, pf_loads); atomicAdd(stats + 12, pf_slow); atomicAdd(stats + 13, pf_slow_clk); atomicAdd(stats + 14, pf_eval);\n        const long gw = blockIdx.x, nw = gridDim.x;\n        stats[16 + gw] = (unsigned long long)(wall_clock64() - pf_start); stats[16 + nw + gw] = pf_pts; stats[16 + 2 * nw + gw] = __popcll(pf_far); stats[16 + 3 * nw + gw] = pf_start; stats[16 + 6 * nw + gw] = pf_t0 - pf_start; stats[16 + 5 * nw + gw] = pf_ex; stats[16 + 7 * nw + gw] = pf_cells | (pf_coarse << 20) | (pf_super << 40); stats[16 + 8 * nw + gw] = pf_flush | (pf_scan_clk << 24); stats[16 + 4 * nw + gw] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);\n    }\n'
+         '        atomicAdd(stats + 9, pf_far != 0ull ? 1ull : 0ull); atomicAdd(stats + 10, pf_load_clk); atomicAdd(stats + 11, pf_loads); atomicAdd(stats + 12, pf_slow); atomicAdd(stats + 13, pf_slow_clk); atomicAdd(stats + 14, pf_eval);\n        const long gw = blockIdx.x, nw = gridDim.x;\n        stats[16 + gw] = (unsigned long long)(wall_clock64() - pf_start); stats[16 + nw + gw] = pf_pts; stats[16 + 2 * nw + gw] = __popcll(pf_far); stats[16 + 3 * nw + gw] = pf_start; stats[16 + 6 * nw + gw] = pf_shell; stats[16 + 5 * nw + gw] = pf_ex; stats[16 + 7 * nw + gw] = pf_cells | (pf_coarse << 20) | (pf_super << 40); stats[16 + 8 * nw + gw] = pf_flush | (pf_scan_clk << 24); stats[16 + 4 * nw + gw] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);\n    }\n'
          '    if (stats != nullptr) {             // [0] candidates examined')], []),
     'knn_g15': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(1.5 * cbrt((double)n));')], []),
     'knn_g20': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(2.0 * cbrt((double)n));')], []),
