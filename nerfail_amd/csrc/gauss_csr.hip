@@ -520,10 +520,21 @@ static size_t cub_temp_bytes(long n) {
     return bytes;
 }
 
-// Content fingerprint of B equally sized items (32-bit words): out[2b] = sum of the words, out[2b+1] = sum of word * (1 +
-// position mod 65521) - order-sensitive - both modulo 2^64. The host keys per-view inverted indices on it when a map arrives
-// as an anonymous tensor (a DataLoader hands out a fresh tensor every iteration: neither its address nor a version
-// counter says which view it is).
+// Content fingerprint of B equally sized items (32-bit words): out[2b], out[2b+1] = two sums (mod 2^64) of 32-bit hashes of
+// (word, position) - every word is mixed NON-LINEARLY with its full position (murmur3 finaliser, two different position
+// multipliers) before it is added, so moved, swapped or compensating values change the sums (a plain sum / position-weighted
+// sum does not see a swap of two equal-weight positions or +d / -d at positions of equal weight). The sums are order-free
+// across threads. The host keys per-view inverted indices on it when a map arrives as an anonymous tensor (a DataLoader hands
+// out a fresh tensor every iteration: neither its address nor a version counter says which view it is).
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ void fp_add(unsigned word, long pos, unsigned long long& s0, unsigned long long& s1) {
+    const unsigned p = (unsigned)pos, q = (unsigned)(pos >> 32);
+    s0 += fmix32(word ^ fmix32(p * 0x9e3779b1u + q + 1u));
+    s1 += fmix32((word + 0x7f4a7c15u) ^ fmix32(p * 0x85ebca77u + q + 0x165667b1u));
+}
 __global__ __launch_bounds__(256) void fingerprint_kernel(const unsigned* __restrict__ data, long words, unsigned long long* __restrict__ out) {
     const long b = blockIdx.y;
     const unsigned* __restrict__ d = data + b * words;
@@ -533,15 +544,9 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(const unsigned* __rest
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
         const uint4 v = d4[q];
         const long i = 4 * q;
-        s0 += (unsigned long long)v.x + v.y + v.z + v.w;
-        s1 += (unsigned long long)v.x * (unsigned long long)(1 + i % 65521) + (unsigned long long)v.y * (unsigned long long)(1 + (i + 1) % 65521) +
-              (unsigned long long)v.z * (unsigned long long)(1 + (i + 2) % 65521) + (unsigned long long)v.w * (unsigned long long)(1 + (i + 3) % 65521);
+        fp_add(v.x, i, s0, s1); fp_add(v.y, i + 1, s0, s1); fp_add(v.z, i + 2, s0, s1); fp_add(v.w, i + 3, s0, s1);
     }
-    for (long i = 4 * quads + (long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long)gridDim.x * blockDim.x) {
-        const unsigned long long v = d[i];
-        s0 += v;
-        s1 += v * (unsigned long long)(1 + i % 65521);
-    }
+    for (long i = 4 * quads + (long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (long)gridDim.x * blockDim.x) fp_add(d[i], i, s0, s1);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
     __shared__ unsigned long long part[2][4];         // one pair of atomics per WORKGROUP: they all land on 2 addresses per item

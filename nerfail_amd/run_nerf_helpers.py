@@ -169,6 +169,7 @@ class NeRF(nn.Module):
         """fp16 hi/lo weight image of the split-precision kernel (nerfail_mlp_pack_f16), cached like packed()."""
         params = list(self.parameters())
         key = tuple((p.data_ptr(), p._version) for p in params)
+        self._f16_poll()                                  # an earlier pack's range check, if its value has arrived
         if self._packed16 is not None and key == self._packed16_key:
             return self._packed16
         lib = _lib.load()
@@ -185,17 +186,43 @@ class NeRF(nn.Module):
 
     F16X3_MAX_WEIGHT = 60.0       # the split-precision image holds fp16(w * 2^10): |w| * 1024 must stay below 65504
 
-    def check_f16x3_range(self, every=64):
+    def check_f16x3_range(self, sync=False):
         """The 'f16x3' kernels pre-scale the weights by 2^10 before the fp16 hi/lo split: a weight of magnitude >= ~64 would
-        become inf (and its lo part NaN) - silently wrong results in a mode advertised as fp32-equivalent. Checked on the
-        first pack and then every `every`-th one (one small device->host read; training re-packs after every step, and
-        Adam moves a weight by <= lr per step). Activations are bounded by the same mechanism only through the weights:
-        NeRF activations are O(1..100), fp16 range is 65504."""
-        self._f16_checks = getattr(self, '_f16_checks', -1) + 1
-        if self._f16_checks % every:
-            return
+        become inf (and its lo part NaN) - silently wrong results in a mode advertised as fp32-equivalent. EVERY pack
+        measures max |weight| on the device (three small kernels). The first pack of a model waits for the value; later ones
+        (training re-packs after every optimizer step) copy it to pinned host memory without stalling the stream and the
+        NEXT call that touches the split-precision image (`packed_f16`, the transposed image, this method) looks at it: a
+        weight that leaves the range is reported one forward later at the latest, whatever changed it (optimizer step,
+        load_state_dict, a manual edit). sync=True waits for the value of this call. Activations are bounded by the same
+        mechanism only through the weights: NeRF activations are O(1..100), fp16 range is 65504."""
+        self._f16_poll()
+        ws = [p.detach() for n_, p in self.named_parameters() if n_.endswith('weight')]
         with torch.no_grad():
-            m = max(float(p.detach().abs().max()) for n_, p in self.named_parameters() if n_.endswith('weight'))
+            m = torch.stack(torch._foreach_norm(ws, float('inf'))).max()
+        if sync or not m.is_cuda or not getattr(self, '_f16_checked_once', False):
+            self._f16_checked_once = True
+            self._f16_verdict(float(m))
+            return
+        host = getattr(self, '_f16_host', None)
+        if host is None:
+            host = self._f16_host = torch.empty((1,), dtype=torch.float32).pin_memory()
+        host.copy_(m.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._f16_pending = ev
+
+    def _f16_poll(self, wait=False):
+        """Looks at the max |weight| an earlier pack measured, if it has arrived (or waits for it)."""
+        ev = getattr(self, '_f16_pending', None)
+        if ev is None:
+            return
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            self._f16_pending = None
+            self._f16_verdict(float(self._f16_host[0]))
+
+    def _f16_verdict(self, m):
         if not m < self.F16X3_MAX_WEIGHT:          # (also catches NaN)
             raise ValueError("NeRF.precision = 'f16x3': max |weight| = %g is outside the range of the split-precision kernels "
                              "(|w| < %g); use precision = 'f32'" % (m, self.F16X3_MAX_WEIGHT))

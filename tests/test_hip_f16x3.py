@@ -166,3 +166,13 @@ def test_f16x3_rejects_weights_outside_its_range():
         _mlp_points(net, pts, vd)
     net.precision = 'f32'
     assert torch.isfinite(_mlp_points(net, pts, vd)).all()
+    # EVERY later pack is checked too (without a stall: reported by the next call), whatever changed the weights
+    _, net = hip_nerf(4, 64, 12, precision='f16x3')
+    assert torch.isfinite(_mlp_points(net, pts, vd)).all()                  # first pack: in range
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    sd['views_linears.0.weight'][2, 7] = -90.0
+    net.load_state_dict(sd)
+    with pytest.raises(ValueError, match='f16x3'):
+        _mlp_points(net, pts, vd)                                           # this pack measures ...
+        torch.cuda.synchronize()
+        _mlp_points(net, pts, vd)                                           # ... and the next call reports

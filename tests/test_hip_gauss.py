@@ -437,6 +437,45 @@ def test_views_resident_by_id_ignore_the_passed_host_tensors(tmp_path):
     assert torch.equal(first, ref) and torch.equal(later, ref)
 
 
+def test_fingerprint_mixes_every_word_with_its_position():
+    """the content key of a map is two sums of murmur-finalised (word, position) hashes - restated here in
+    numpy -, so swapping two words, moving a value or +d / -d at two positions all change it (the round-2 checksum, a plain
+    sum + a sum weighted by position mod 65521, saw none of these at positions of equal weight)."""
+    from nerfail_amd import GaussNet as G
+    rs = np.random.RandomState(3)
+    base = rs.randint(0, 2 ** 31, size=(1, 2, 40, 41, 8)).astype(np.int32)          # 26 240 words per map, 16-byte aligned
+
+    def fmix(h):
+        h = h.astype(np.uint64)
+        for sh, mul in ((16, 0x85ebca6b), (13, 0xc2b2ae35)):
+            h ^= h >> np.uint64(sh)
+            h = (h * np.uint64(mul)) & np.uint64(0xffffffff)
+        return h ^ (h >> np.uint64(16))
+
+    def ref(words):
+        w = words.reshape(-1).view(np.uint32).astype(np.uint64)
+        pos = np.arange(w.size, dtype=np.uint64)
+        m32 = np.uint64(0xffffffff)
+        a = fmix(w ^ fmix((pos * np.uint64(0x9e3779b1) + np.uint64(1)) & m32))
+        b = fmix(((w + np.uint64(0x7f4a7c15)) & m32) ^ fmix((pos * np.uint64(0x85ebca77) + np.uint64(0x165667b1)) & m32))
+        return int(a.sum() & np.uint64(0xffffffffffffffff)), int(b.sum() & np.uint64(0xffffffffffffffff))
+
+    def fp(words):
+        k = G.fingerprints(T(words.view(np.float32)))[0]
+        return k[1] & 0xffffffffffffffff, k[2] & 0xffffffffffffffff
+
+    assert fp(base) == ref(base)
+    flat = base.reshape(-1)
+    swapped = flat.copy(); swapped[[5, 5 + 65521 % flat.size]] = swapped[[5 + 65521 % flat.size, 5]]
+    plus_minus = flat.copy(); plus_minus[7] += 9; plus_minus[8] -= 9
+    moved = np.roll(flat, 4)
+    seen = {fp(base)}
+    for other in (swapped, plus_minus, moved):
+        k = fp(other.reshape(base.shape))
+        assert k == ref(other) and k not in seen
+        seen.add(k)
+
+
 def test_view_ids_are_checked_and_stale_sidecars_are_rebuilt(tmp_path):
     """ADVICE r2 (medium x2): (i) an id reused for a view of another resolution raises instead of reading out of bounds, an
     id whose registered index belongs to another map is caught by the fingerprint on first use, register_view_index
