@@ -566,11 +566,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void kn
         if ((threadIdx.x & 63) == 0) { atomicAdd(stats, tot); atomicAdd(stats + 1, searched); }
     }
     if (!valid) return;
+    // 32 bytes per query and output as two 16-byte stores (eight 4-byte stores 32 bytes apart wrote every 64-byte line of the
+    // outputs in pieces: 5x the bytes at the memory side)
+    float d[8], jf[8];
+    int ji[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        dist[8 * qi + k] = sqrt_rn(key_d2(fk[k]));
-        if (idx_f != nullptr) idx_f[8 * qi + k] = (float)(int)(unsigned)fk[k];
-        if (idx_i != nullptr) idx_i[8 * qi + k] = (int)(unsigned)fk[k];
+        d[k] = sqrt_rn(key_d2(fk[k]));
+        ji[k] = (int)(unsigned)fk[k];
+        jf[k] = (float)ji[k];
+    }
+    float4* __restrict__ od = reinterpret_cast<float4*>(dist + 8 * qi);
+    od[0] = make_float4(d[0], d[1], d[2], d[3]);
+    od[1] = make_float4(d[4], d[5], d[6], d[7]);
+    if (idx_f != nullptr) {
+        float4* __restrict__ of = reinterpret_cast<float4*>(idx_f + 8 * qi);
+        of[0] = make_float4(jf[0], jf[1], jf[2], jf[3]);
+        of[1] = make_float4(jf[4], jf[5], jf[6], jf[7]);
+    }
+    if (idx_i != nullptr) {
+        int4* __restrict__ oi = reinterpret_cast<int4*>(idx_i + 8 * qi);
+        oi[0] = make_int4(ji[0], ji[1], ji[2], ji[3]);
+        oi[1] = make_int4(ji[4], ji[5], ji[6], ji[7]);
     }
 }
 
@@ -685,6 +702,8 @@ static int grid_search(const float* queries, int64_t n_queries, int view_h, int 
     if (n_queries == 0) return NERFAIL_OK;
     NF_REQUIRE(queries != nullptr && dist != nullptr, "NULL pointer");
     NF_REQUIRE(idx_f32 != nullptr || idx_i32 != nullptr, "need idx_f32 or idx_i32");
+    NF_REQUIRE(((reinterpret_cast<uintptr_t>(dist) | reinterpret_cast<uintptr_t>(idx_f32) | reinterpret_cast<uintptr_t>(idx_i32)) & 15) == 0,
+               "dist / idx must be 16-byte aligned");
     NF_REQUIRE(workspace != nullptr && workspace_bytes >= nerfail_knn8_grid_workspace_bytes(n_points),
                "workspace too small (nerfail_knn8_grid_workspace_bytes)");
     const GridWs w = carve(const_cast<void*>(workspace), n_points);
