@@ -135,6 +135,8 @@ EXPERIMENTS = {
          '        atomicAdd(stats + 6, pf_super); atomicAdd(stats + 7, pf_scan_clk); atomicAdd(stats + 8, (unsigned long long)(wall_clock64() - pf_t0));\n'
          '        atomicAdd(stats + 9, pf_far != 0ull ? 1ull : 0ull); atomicAdd(stats + 10, pf_load_clk); atomicAdd(stats + 11, pf_loads); atomicAdd(stats + 12, pf_slow); atomicAdd(stats + 13, pf_slow_clk); atomicAdd(stats + 14, pf_eval);\n        const long gw = blockIdx.x, nw = gridDim.x;\n        stats[16 + gw] = (unsigned long long)(wall_clock64() - pf_start); stats[16 + nw + gw] = pf_pts; stats[16 + 2 * nw + gw] = __popcll(pf_far); stats[16 + 3 * nw + gw] = pf_start; stats[16 + 6 * nw + gw] = pf_shell; stats[16 + 5 * nw + gw] = pf_ex; stats[16 + 7 * nw + gw] = pf_cells | (pf_coarse << 20) | (pf_super << 40); stats[16 + 8 * nw + gw] = pf_flush | (pf_scan_clk << 24); stats[16 + 4 * nw + gw] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);\n    }\n'
          '    if (stats != nullptr) {             // [0] candidates examined')], []),
+    'knn_g075': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(0.75 * cbrt((double)n));')], []),
+    'knn_g05': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(0.5 * cbrt((double)n));')], []),
     'knn_g15': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(1.5 * cbrt((double)n));')], []),
     'knn_g20': ('knn_grid.hip', [('    int G = (int)lround(cbrt((double)n));', '    int G = (int)lround(2.0 * cbrt((double)n));')], []),
     # K6 sample_fine pricing: no output stores / no merge search / no inverse-cdf search / no double-precision scan

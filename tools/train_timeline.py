@@ -8,7 +8,7 @@ import glob
 import os
 import sys
 
-BIG = ('nerf_mlp_fwd', 'nerf_mlp_bwd_data', 'nerf_mlp_bwd_weights')
+BIG = ('nerf_mlp_fwd', 'nerf_mlp_bwd_data', 'nerf_mlp_bwd_weights', 'nerf_mlp_dw_lds')
 
 
 def main():
