@@ -27,21 +27,21 @@ def main():
     sd, coarse = hip_nerf(8, 256, 31, requires_grad=True)
     _, fine = hip_nerf(8, 256, 32, requires_grad=True)
     cap = []
-    orig_bwd, orig_fwd = _train.mlp_backward, _train.mlp_fwd_train
+    orig_bwd2, orig_fwd_rays = _train.mlp_backward2, _train.mlp_fwd_train_rays
 
-    def fwd(net, pts, viewdirs):
-        cap.append(('f', net, pts.clone(), viewdirs.clone()))
-        return orig_fwd(net, pts, viewdirs)
+    def fwd_rays(net, rays_, z_vals, acts=None):          # the training pipeline forms the sample points inside the kernel
+        cap.append(('f', net, (rays_[:, None, 0:3] + rays_[:, None, 3:6] * z_vals[..., None]).clone(), rays_[:, 8:11].clone()))
+        return orig_fwd_rays(net, rays_, z_vals, acts)
 
-    def bwd(net, d_raw, acts, grads):
-        cap.append(('b', net, d_raw.clone()))
-        return orig_bwd(net, d_raw, acts, grads)
-    _train.mlp_fwd_train, _train.mlp_backward = fwd, bwd
+    def bwd2(net0, d_raw, acts, grads0, M0, net1, grads1, M1, accumulate=False):       # coarse + fine in one launch
+        cap.append(('b', net0, d_raw[:M0].clone()))
+        return orig_bwd2(net0, d_raw, acts, grads0, M0, net1, grads1, M1, accumulate)
+    _train.mlp_fwd_train_rays, _train.mlp_backward2 = fwd_rays, bwd2
     r = RN.render_rays(rays, coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.)
     (RN.img2mse(r['rgb_map'], target) + RN.img2mse(r['rgb0'], target)).backward()
-    _train.mlp_fwd_train, _train.mlp_backward = orig_fwd, orig_bwd
+    _train.mlp_fwd_train_rays, _train.mlp_backward2 = orig_fwd_rays, orig_bwd2
     pts, dirs = [(c[2], c[3]) for c in cap if c[0] == 'f' and c[1] is coarse][0]
-    d_raw = [c[2] for c in cap if c[0] == 'b' and c[1] is coarse][0]
+    d_raw = [c[2] for c in cap if c[0] == 'b' and c[1] is coarse][0].reshape(pts.shape[0], pts.shape[1], 4)
     R, N = pts.shape[0], pts.shape[1]
     flat_dirs = dirs[:, None, :].expand(R, N, 3).reshape(-1, 3) if dirs.dim() == 2 else dirs.reshape(-1, 3)
 
