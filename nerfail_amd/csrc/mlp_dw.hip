@@ -691,7 +691,7 @@ int build_descs(int D, int W, const MlpLayout& L, const TrainLayout& TL, const n
 
 // ns per TILE (two k16-steps) of each group shape, FITTED to per-workgroup busy times (tools/dw_balance.py): the
 // partition's cost unit. [0] exact f32, [1] bf16x3.
-const int kTileNs[2][6] = {{7000, 3800, 2200, 800, 780, 1200}, {4060, 2854, 1974, 1102, 1078, 1296}};
+const int kTileNs[2][6] = {{7000, 3800, 2200, 800, 780, 1200}, {2643, 1717, 1361, 933, 924, 1115}};
 
 struct DwPlan {
     DwArgs ka;

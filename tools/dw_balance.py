@@ -13,7 +13,7 @@ import synth
 from nerfail_amd import _lib, _train
 from nerfail_amd.run_nerf_helpers import NeRF
 dev = torch.device('cuda:0')
-K_TILE_NS = [[7000, 3800, 2200, 800, 780, 1200], [4060, 2854, 1974, 1102, 1078, 1296]]   # copy of kTileNs (mlp_dw.hip)
+K_TILE_NS = [[7000, 3800, 2200, 800, 780, 1200], [2643, 1717, 1361, 933, 924, 1115]]   # copy of kTileNs (mlp_dw.hip)
 R, NC, NF = 1024, 64, 192
 
 
