@@ -134,7 +134,7 @@ __device__ __forceinline__ float lane63(float v) { return __int_as_float(__built
 
 // One step of the segmented scan: every lane looks at the lane the DPP control names (a lane without a source - row
 // start, masked row - sees key -2, which no entry has) and adds that lane's sums if it holds the same key.
-template <int CTRL, int ROW_MASK = 0xF, int C>
+template <int CTRL, int ROW_MASK = 0xF, bool W4 = true, int C>
 __device__ __forceinline__ void seg_scan_step(const int key, float4 (&v)[C]) {
     const int key_src = __builtin_amdgcn_update_dpp(-2, key, CTRL, ROW_MASK, 0xF, false);
     const bool same = key_src == key;
@@ -143,8 +143,11 @@ __device__ __forceinline__ void seg_scan_step(const int key, float4 (&v)[C]) {
         const float ax = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].x), CTRL, ROW_MASK, 0xF, false));
         const float ay = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].y), CTRL, ROW_MASK, 0xF, false));
         const float az = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].z), CTRL, ROW_MASK, 0xF, false));
-        const float aw = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].w), CTRL, ROW_MASK, 0xF, false));
-        if (same) { v[c].x += ax; v[c].y += ay; v[c].z += az; v[c].w += aw; }
+        if (same) { v[c].x += ax; v[c].y += ay; v[c].z += az; }
+        if constexpr (W4) {                                             // (the rgb-only step path carries no fourth channel)
+            const float aw = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].w), CTRL, ROW_MASK, 0xF, false));
+            if (same) v[c].w += aw;
+        }
     }
 }
 
@@ -155,7 +158,7 @@ __device__ __forceinline__ void seg_scan_step(const int key, float4 (&v)[C]) {
 // starts a row), `row_of` holds ONE int per chunk (the ordinal of the row the chunk's first entry belongs to), and an
 // entry's key - its row's ordinal - is that plus the number of row starts up to the entry (a ballot and a bit count per
 // 64 entries): 8 bytes per entry instead of 12.
-template <int C, bool PACKED>
+template <int C, bool PACKED, bool W4 = true>
 __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, const long E, const int* __restrict__ row_of,
                                                  const int* __restrict__ contrib, const float* __restrict__ w_sorted,
                                                  const float4* __restrict__ g_pix, const int accumulate,
@@ -240,7 +243,7 @@ __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, 
             float4 v[C];
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                v[c] = key[u] != kSegNone ? make_float4(w[u] * g[u][c].x, w[u] * g[u][c].y, w[u] * g[u][c].z, w[u] * g[u][c].w)
+                v[c] = key[u] != kSegNone ? make_float4(w[u] * g[u][c].x, w[u] * g[u][c].y, w[u] * g[u][c].z, W4 ? w[u] * g[u][c].w : 0.f)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);   // (keeps 0 * inf of a clamped lane out)
             // inclusive segmented scan over the 64 lanes (keys are sorted: equal keys are contiguous), on DPP moves:
             // Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the last lane of a row handed to the
@@ -248,12 +251,12 @@ __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, 
             // everything between it and me has that key too, so its sum is exactly what my run is missing.
             // (__shfl_up is ds_bpermute_b32 on gfx9: 36 trips through the CU's LDS crossbar per 64 entries kept this
             // kernel at 186 us per 8-view batch whatever its HBM traffic was.)
-            seg_scan_step<0x111>(key[u], v);
-            seg_scan_step<0x112>(key[u], v);
-            seg_scan_step<0x114>(key[u], v);
-            seg_scan_step<0x118>(key[u], v);
-            seg_scan_step<0x142, 0xA>(key[u], v);
-            seg_scan_step<0x143, 0xC>(key[u], v);
+            seg_scan_step<0x111, 0xF, W4>(key[u], v);
+            seg_scan_step<0x112, 0xF, W4>(key[u], v);
+            seg_scan_step<0x114, 0xF, W4>(key[u], v);
+            seg_scan_step<0x118, 0xF, W4>(key[u], v);
+            seg_scan_step<0x142, 0xA, W4>(key[u], v);
+            seg_scan_step<0x143, 0xC, W4>(key[u], v);
             const int key0 = __builtin_amdgcn_readlane(key[u], 0);
             if (key[u] == key0 && key0 == carry_row) {                 // the run carried over from the previous 64 entries
 #pragma unroll
@@ -279,7 +282,7 @@ __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, 
             carry_row = __builtin_amdgcn_readlane(key[u], 63);         // the run of the last lane stays open
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                carry[c] = make_float4(lane63(v[c].x), lane63(v[c].y), lane63(v[c].z), lane63(v[c].w));
+                carry[c] = make_float4(lane63(v[c].x), lane63(v[c].y), lane63(v[c].z), W4 ? lane63(v[c].w) : 0.f);
         }
     }
     if (lane == 0 && carry_row != kSegNone) {                          // the run still open at the end of the chunk
@@ -335,6 +338,7 @@ struct SegViews {
 // per-pixel gradients (10 MB, swept in step with the rows) instead of all of them at once: with the plain (x = chunk,
 // y = view) grid the 16-byte gathers were re-fetched 3.5 times (729 MB of L2 fills per 8-view batch for 205 MB of
 // algorithmic bytes, rocprofv3 FETCH_SIZE) and the kernel ran at the fabric's rate.
+template <bool W4>
 __global__ __launch_bounds__(256) void gauss_seg_reduce_views_kernel(SegViews a) {
     const long per_xcd = (a.total_blocks + 7) >> 3;
     long vb = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_views_kernel(SegViews a)
         if (i < a.nv && vb >= a.block_start[i]) v = i;                 // block_start ascends
     const long wg = (vb - a.block_start[v]) * 4 + (threadIdx.x >> 6);
     if (wg >= a.chunks[v]) return;                                     // wave-uniform
-    seg_reduce_chunk<1, true>(wg, threadIdx.x & 63, a.E[v], a.chunk_ord[v], a.packed[v], a.w_sorted[v], a.g_pix[v], 0, a.val[v],
-                              a.n_rows[v], a.rec_row[v], a.rec_val[v]);
+    seg_reduce_chunk<1, true, W4>(wg, threadIdx.x & 63, a.E[v], a.chunk_ord[v], a.packed[v], a.w_sorted[v], a.g_pix[v], 0, a.val[v],
+                                  a.n_rows[v], a.rec_row[v], a.rec_val[v]);
 }
 
 // ONE view, C right-hand sides (DeepFool's class gradients), over the view's compact index into val[C][n_rows].
@@ -741,7 +745,8 @@ static int reduce_views(const nerfail_view_index* views, int n_views, long Ns, l
         a.total_blocks = 0;
         for (int i = 0; i < kViewsPerLaunch; ++i) { a.block_start[i] = a.total_blocks; a.total_blocks += a.chunks[i] / 4; }
         if (max_chunks > 0) {
-            gauss_seg_reduce_views_kernel<<<dim3((unsigned)(((a.total_blocks + 7) / 8) * 8)), dim3(256), 0, s>>>(a);
+            if (grad3 != nullptr) gauss_seg_reduce_views_kernel<false><<<dim3((unsigned)(((a.total_blocks + 7) / 8) * 8)), dim3(256), 0, s>>>(a);
+            else gauss_seg_reduce_views_kernel<true><<<dim3((unsigned)(((a.total_blocks + 7) / 8) * 8)), dim3(256), 0, s>>>(a);
             NF_LAUNCHED("gauss_seg_reduce_views_kernel");
             gauss_seg_combine_views_kernel<<<dim3((unsigned)((max_chunks + 255) / 256), (unsigned)nv), dim3(256), 0, s>>>(a);
             NF_LAUNCHED("gauss_seg_combine_views_kernel");

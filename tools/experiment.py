@@ -102,7 +102,7 @@ EXPERIMENTS = {
     'dw_nofetch': ('mlp_dw.hip', [('        R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n', '        if (off == -12345) R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n')], []),
     'dw_norowsum': ('mlp_dw.hip', [('                rowsum[m] = rowsum[m] + (R[P][m][0] + R[P][m][1]);\n', '')], []),
     # K11 segmented reduce pricing: no wave scan (wrong sums) / no gathers (index stream only)
-    'seg_noscan': ('gauss_csr.hip', [('            seg_scan_step<0x111>(key[u], v);\n            seg_scan_step<0x112>(key[u], v);\n            seg_scan_step<0x114>(key[u], v);\n            seg_scan_step<0x118>(key[u], v);\n            seg_scan_step<0x142, 0xA>(key[u], v);\n            seg_scan_step<0x143, 0xC>(key[u], v);\n', '')], []),
+    'seg_noscan': ('gauss_csr.hip', [('            seg_scan_step<0x111, 0xF, W4>(key[u], v);\n            seg_scan_step<0x112, 0xF, W4>(key[u], v);\n            seg_scan_step<0x114, 0xF, W4>(key[u], v);\n            seg_scan_step<0x118, 0xF, W4>(key[u], v);\n            seg_scan_step<0x142, 0xA, W4>(key[u], v);\n            seg_scan_step<0x143, 0xC, W4>(key[u], v);\n', '')], []),
     'seg_nogather': ('gauss_csr.hip', [('            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> (PACKED ? 1 : 3)) * C + c];', '            for (int c = 0; c < C; ++c) g[u][c] = make_float4((float)id[u], 1.f, 2.f, 3.f);')], []),
     'seg_noemit': ('gauss_csr.hip', [('        if (!owner) return;\n#pragma unroll\n        for (int c = 0; c < C; ++c) {\n            float4 o = v[c];', '        if (!owner || row != -12345) return;\n#pragma unroll\n        for (int c = 0; c < C; ++c) {\n            float4 o = v[c];')], []),
     'seg_u16': ('gauss_csr.hip', [('constexpr int kSegU = 8; ', 'constexpr int kSegU = 16;')], []),
