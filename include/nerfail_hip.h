@@ -240,6 +240,7 @@ int nerfail_knn8_grid_search(const float* queries, int64_t n_queries, int64_t n_
 /* The same search for the [height, width, 3] point image of ONE VIEW (pts_max, NC:418-423 -> CI:126): results in the same
  * row-major [height*width, 8] layout, but a wave searches an 8 x 8 pixel tile instead of 64 consecutive pixels of a row -
  * neighbouring pixels' points lie within a fraction of a grid cell, the 64 searches share their candidates. */
+/* (all grid searches: dist / idx_f32 / idx_i32 must be 16-byte aligned - a query's eight results leave as two 16-byte stores) */
 int nerfail_knn8_grid_search_view(const float* queries, int height, int width, int64_t n_points, float* dist, float* idx_f32,
                                   int32_t* idx_i32, const void* workspace, size_t workspace_bytes, void* stream);
 /* Work counters of the grid search (measurement aid, off by default): while `stats` (two device uint64, zeroed by the caller)
