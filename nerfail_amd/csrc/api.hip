@@ -1,7 +1,9 @@
 // Library-wide plumbing: error state, version, device query.
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 namespace nerfail {
 
@@ -17,6 +19,28 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what) {
     set_error("%s: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
     return NERFAIL_EHIP;
+}
+
+static int trace_level_from_env() {
+    const char* v = getenv("NERFAIL_TRACE");
+    return v ? atoi(v) : 0;
+}
+int g_trace = trace_level_from_env();
+
+int trace_launch(const char* name) {
+    char buf[160];
+    int n = snprintf(buf, sizeof(buf), "[nerfail] %s", name);
+    if (write(2, buf, n) < 0) return 0;
+    if (g_trace >= 2) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            if (write(2, " FAILED\n", 8) < 0) return 0;
+            return hip_fail(e, name);
+        }
+        if (write(2, " ok", 3) < 0) return 0;
+    }
+    if (write(2, "\n", 1) < 0) return 0;
+    return 0;
 }
 
 }  // namespace nerfail

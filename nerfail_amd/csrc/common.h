@@ -12,6 +12,10 @@ namespace nerfail {
 
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+// Launch trace (debug aid, env NERFAIL_TRACE): 1 = write every launched kernel's name to stderr, unbuffered;
+// 2 = also hipDeviceSynchronize() after the launch and write " ok" - the last name without "ok" is the kernel that faulted.
+extern int g_trace;
+int trace_launch(const char* name);
 
 #define NF_REQUIRE(cond, msg)                                   \
     do {                                                        \
@@ -26,6 +30,10 @@ int hip_fail(hipError_t e, const char* what);
     do {                                                        \
         hipError_t e__ = hipGetLastError();                     \
         if (e__ != hipSuccess) return ::nerfail::hip_fail(e__, name); \
+        if (::nerfail::g_trace) {                               \
+            int t__ = ::nerfail::trace_launch(name);            \
+            if (t__) return t__;                                \
+        }                                                       \
     } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

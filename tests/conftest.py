@@ -46,6 +46,13 @@ def pytest_configure(config):
                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
 
 
+def pytest_sessionstart(session):
+    # guard-page mode (tests/guard): must replace torch's allocator before the first device allocation of the run
+    import guard
+    if guard.wanted():
+        guard.install()
+
+
 def pytest_unconfigure(config):
     global _LAUNCHER
     if _LAUNCHER is not None:
