@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NERFAIL_ABI_VERSION 4
+#define NERFAIL_ABI_VERSION 5
 
 #define NERFAIL_OK 0
 #define NERFAIL_EINVAL 1   /* bad argument (null pointer, size, unsupported shape) */
@@ -254,6 +254,11 @@ int nerfail_knn8_grid_stats(unsigned long long* stats);
 /* create_gauss_w.forward, GN:169-186 (driver DW:82-97): dist_and_index[B,2,P,8] -> out[B,2,P,8]
  * (weight, index) with g = exp(-(d/c)^2/2), w = g/(sum g + 0.001) if sum g > 0 else 0. P = H*W. */
 int nerfail_gauss_weight(const float* dist_and_index, int64_t B, int64_t P, float c, float* out, void* stream);
+
+/* gauss_get_img.forward's hot part, GN:309-319: x_rgba[n,4] from an already gathered r[n,4] (gauss_get_r's output, GN:224-268)
+ * and ori_img[n,4] (float BGRA): rgb = ori_rgb + r_rgb * (r_a/255) where ori_a > 0 else 0, a = ori_a. Unlike gauss_net's
+ * composite (nerfail_gauss_fwd) there is neither an epsilon clip nor a [0,255] clip. x_rgba may alias nothing. */
+int nerfail_gauss_compose(const float* ori_img, const float* r, int64_t n_pixels, float* x_rgba, void* stream);
 
 /* gauss_net.forward hot part, GN:53-119. spatial[Ns,4] (BGRA, 0..255), weight_and_index[B,2,P,8],
  * ori_img[B,P,4] float. epsilon < 0 means None (no clip). Writes x[B,P,4], x_rgba[B,P,4];

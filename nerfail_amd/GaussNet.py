@@ -269,6 +269,8 @@ def register_view_index(view_id, index, Ns=None, replace=False):
 # and ignores the tensors it was handed.
 _VIEW_MAPS = {}                      # key -> [2,H,W,8] float32 device tensor, insertion order = LRU order
 _VIEW_ORI = {}                       # key -> [H,W,4] uint8 (or float32) device tensor
+_VIEW_ORI_EPOCH = {}                 # key -> how often the resident image of that id was (re)registered: part of the logit-cache key
+_VIEW_PASSED_OK = set()              # keys whose resident map was compared once with a map the caller passed under that id
 VIEW_MAPS_BYTES = 96 << 30
 
 
@@ -293,10 +295,12 @@ def register_view(view_id, Ns, weight_and_index=None, ori_img=None):
             raise ValueError('a view map must be [2,H,W,8] (DW:95-97)')
         view_indices([wi], Ns, [view_id])
         _lru_put(_VIEW_MAPS, key, wi, VIEW_MAPS_BYTES)
+        _VIEW_PASSED_OK.discard(key)
     if ori_img is not None:
         o = torch.as_tensor(ori_img)
         o = o.to(dev).contiguous() if o.dtype == torch.uint8 else _lib.f32c(o, dev)
         _lru_put(_VIEW_ORI, key, o, VIEW_MAPS_BYTES)
+        _VIEW_ORI_EPOCH[key] = _VIEW_ORI_EPOCH.get(key, 0) + 1      # cached original-image logits of this id are stale now
     return key
 
 
@@ -377,6 +381,19 @@ def resolve_views(spatial_rgb, weight_and_index_list, ori_img, view_ids=None, ke
     res_wi = [_VIEW_MAPS.get(k) if k is not None else None for k in keys]
     res_ori = [_VIEW_ORI.get(k) if k is not None else None for k in keys]
     batch_wi = batch_ori = None
+    # A resident view wins over the tensor the caller passes under the same id (that is the point: the reference-shaped loop
+    # hands over freshly loaded tensors every iteration). ONCE per id the passed map - if it is a device tensor, i.e. free to
+    # look at - is compared with the resident one by content fingerprint, so that an id reused for another scene / split or a
+    # regenerated map file raises instead of silently differentiating through the wrong view.
+    if view_ids is not None and isinstance(wi_in, torch.Tensor) and wi_in.is_cuda and wi_in.dim() == 5 and wi_in.shape[0] == B:
+        todo = [b for b, k in enumerate(keys) if res_wi[b] is not None and k not in _VIEW_PASSED_OK]
+        if todo and wi_in.dtype == torch.float32 and wi_in.is_contiguous():
+            got = fingerprints(wi_in)
+            for b in todo:
+                if tuple(wi_in.shape[1:]) != tuple(res_wi[b].shape) or got[b] != fingerprints(res_wi[b].unsqueeze(0))[0]:
+                    raise ValueError('view id %r is resident with a DIFFERENT map than the one passed under that id (reused id or '
+                                     'regenerated map file): register_view(..., weight_and_index=) to replace it' % (view_ids[b],))
+                _VIEW_PASSED_OK.add(keys[b])
     if any(w is None for w in res_wi):
         if wi_in is None:
             raise KeyError('a view of the batch is not resident and no weight_and_index_list was passed')
@@ -639,7 +656,8 @@ class gauss_net(nn.Module):
         _, x_rgba, aux = hot_forward(s, views, self.epsilon, self._mm() if self.update_epsilon_3d else None, need_x=False, need_aux=True)
         x_rgba.requires_grad_(True)
         vids = views.view_ids
-        key = ('ids', tuple(_view_key(v, views.Ns) for v in vids)) if vids is not None else views.ori_src
+        key = (('ids', tuple((k_, _VIEW_ORI_EPOCH.get(k_, 0)) for k_ in (_view_key(v, views.Ns) for v in vids)))
+               if vids is not None else views.ori_src)
         self._ori_keep_src = getattr(views, '_ori_keep', None)
         cla, ori_cla = self.cold_tail(x_rgba, views.ori_float, ori_key=key)
         self._ori_keep_src = None
@@ -683,6 +701,102 @@ class gauss_net(nn.Module):
         _lib.check(lib.nerfail_gauss_bwd_view_multi(_lib.dev(ori), _lib.dev(x_c), _lib.dev(J), C, ctypes.byref(st), n, P, eps,
                                                     _lib.dev(scratch), _lib.dev(out), _lib.stream()))
         return out.reshape((C,) + tuple(spatial_rgb.shape))
+
+
+class _Compose(torch.autograd.Function):
+    """x_rgba = compose(ori, r) of gauss_get_img (GN:309-319) on nerfail_gauss_compose; the gradient w.r.t. r is the plain chain
+    rule of those three lines (elementwise, cold: nobody differentiates this in the reference's scripts)."""
+
+    @staticmethod
+    def forward(ctx, ori, r):
+        out = torch.empty_like(r)
+        _lib.check(_lib.load().nerfail_gauss_compose(_lib.dev(ori, 'ori_img'), _lib.dev(r, 'r'), r.numel() // 4, _lib.dev(out), _lib.stream()))
+        ctx.save_for_backward(ori, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ori, r = ctx.saved_tensors
+        opaque = (ori[..., 3:4] > 0).to(g.dtype)
+        g_rgb = g[..., :3] * opaque
+        g_r = torch.cat([g_rgb * (r[..., 3:4] / 255), (g_rgb * r[..., :3]).sum(-1, keepdim=True) / 255], -1)
+        return None, g_r
+
+
+class gauss_get_r(nn.Module):
+    """GN:189-268: the perturbation gathered onto the pixels of a batch of views straight from RAW distances,
+    r = sum_k s[idx_k] g_k / (sum g + 0.001), g = exp(-(d/c)^2 / 2). Composition of K9 (nerfail_gauss_weight) and K10's gather
+    (nerfail_gauss_fwd: its `x` output), differentiable w.r.t. spatial_rgb like the reference's."""
+
+    def __init__(self, device, c, model, model_name):
+        super(gauss_get_r, self).__init__()
+        self.top_number = 8
+        self.c = torch.nn.Parameter(torch.tensor([c]), requires_grad=False)
+        self.device = device
+        self.model = model
+        self.model_name = model_name
+        self.w = 299
+        self.h = 299
+        self.update_epsilon_3d = True
+        self._eps_minmax = None
+
+    _mm = gauss_net._mm
+    epsilon_3d_max = gauss_net.epsilon_3d_max
+    epsilon_3d_min = gauss_net.epsilon_3d_min
+    epsilon_3d_zero = gauss_net.epsilon_3d_zero
+    close_update_epsilon_3d = gauss_net.close_update_epsilon_3d
+    open_update_epsilon_3d = gauss_net.open_update_epsilon_3d
+    print_epsilon = gauss_net.print_epsilon
+
+    def forward(self, spatial_rgb, dist_and_index_list):
+        dev = _cuda()
+        dai = _lib.f32c(dist_and_index_list, dev)
+        if dai.dim() != 5 or dai.shape[1] != 2 or dai.shape[4] != 8:
+            raise ValueError('dist_and_index_list must be [B,2,H,W,8] (CI:148-163)')
+        if not float(self.c) > 0:
+            raise _lib.NerfailError('gauss_get_r: c must be positive')
+        wi = torch.ops.nerfail_mi.gauss_weight(dai, float(self.c))                         # K9
+        ori0 = torch.zeros((dai.shape[0], dai.shape[2], dai.shape[3], 4), dtype=torch.float32, device=dev)   # r does not depend on the image
+        x, _ = gauss_gather(spatial_rgb, wi, ori0, None, self._mm() if self.update_epsilon_3d else None, True)
+        return x
+
+
+class gauss_get_img(nn.Module):
+    """GN:271-337: composite an already gathered r onto the images and classify. Hot part = nerfail_gauss_compose (no epsilon
+    clip, no [0,255] clip - GN:309-319); the tail (NHWC -> NCHW, white background, Resize to 299 / 224 - here ALSO for
+    "my_model", GN:339-347 - and the two classifier passes) is stock PyTorch like gauss_net's."""
+
+    def __init__(self, device, c, model, model_name):
+        super(gauss_get_img, self).__init__()
+        self.top_number = 8
+        self.c = torch.nn.Parameter(torch.tensor([c]), requires_grad=False)
+        self.device = device
+        self.model = model
+        self.model_name = model_name
+        self.w = 299
+        self.h = 299
+
+    _resize = gauss_net._resize
+
+    def compose(self, ori_img, r):
+        """(ori_img float [B,H,W,4], x_rgba): the part before the classifier."""
+        dev = _cuda()
+        ori = _lib.f32c(torch.as_tensor(ori_img), dev)                                     # GN:290
+        r_ = r if (isinstance(r, torch.Tensor) and r.is_cuda and r.dtype == torch.float32 and r.is_contiguous()) else _lib.f32c(torch.as_tensor(r), dev)
+        if ori.dim() != 4 or ori.shape[-1] != 4 or tuple(r_.shape) != tuple(ori.shape):
+            raise ValueError('ori_img and r must both be [B,H,W,4], got %s and %s' % (tuple(ori.shape), tuple(r_.shape)))
+        return ori, _Compose.apply(ori, r_)
+
+    def forward(self, ori_img, r):
+        ori, x_rgba = self.compose(ori_img, r)
+        size = 224 if self.model_name == "vit_b_16" else 299
+
+        def three(t):
+            c = t.transpose(2, 3).transpose(1, 2)
+            return self._resize(torch.where(c[:, 3:4] > 0, c[:, :3], torch.full_like(c[:, :3], 255.)).contiguous(), size)
+        cla = self.model(three(x_rgba))
+        ori_cla = self.model(three(ori))
+        return r, x_rgba, cla, ori, ori_cla
 
 
 class create_gauss_w(nn.Module):

@@ -31,6 +31,14 @@ def _imread_unchanged(path):
         return np.ascontiguousarray(a[..., [2, 1, 0, 3]])
 
 
+def _file_sig(path):
+    try:
+        st = os.stat(path)
+        return (int(st.st_mtime_ns), int(st.st_size))
+    except OSError:
+        return (0, 0)
+
+
 class ViewList(list):
     """A batch as per-view tensors (no stacking) + the ids under which the views are resident."""
 
@@ -45,7 +53,7 @@ class ViewList(list):
 
 class gauss_dataset(Dataset):
     """MD:187-204. `Ns` (rows of the perturbation table, P*H*W) switches residency on: items are then kept on the device by
-    view id = absolute path of the map file, together with their inverted index."""
+    view id (see view_id), together with their inverted index."""
 
     def __init__(self, all_index_and_dist_name_list, all_img_name_list, all_img_save_to_name_list, all_img_mask_save_to_name_list,
                  device, Ns=None):
@@ -56,12 +64,20 @@ class gauss_dataset(Dataset):
         self.all_img_mask_save_to_name_list = all_img_mask_save_to_name_list
         self.device = device
         self.Ns = Ns
+        self._vids = {}
 
     def __len__(self):
         return self.length
 
     def view_id(self, index):
-        return os.path.abspath(self.all_index_and_dist_name_list[index])
+        """(map path, its mtime_ns and size, the image's mtime_ns and size): a regenerated map or image file is ANOTHER view
+        as far as the device-resident copies and cached logits are concerned (load_view_indices records the same
+        signature in its sidecars)."""
+        vid = self._vids.get(index)
+        if vid is None:                    # taken when the dataset first touches the view (two stat calls), then fixed for its life
+            m, i = self.all_index_and_dist_name_list[index], self.all_img_name_list[index]
+            vid = self._vids[index] = (os.path.abspath(m),) + _file_sig(m) + _file_sig(i)
+        return vid
 
     def __getitem__(self, index):
         dev = _cuda()

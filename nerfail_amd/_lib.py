@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: libnerfail_hip.so binds to 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFAIL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerfail_hip.so')   # override: A/B builds (tools/ablate.py)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DEPTH = 16
 DW_BF16X3, DW_ACCUMULATE = 1, 2          # flags of nerfail_mlp_bwd_weights
 RAY_FLOATS = 11
@@ -81,6 +81,7 @@ SIGNATURES = {
     'nerfail_knn8_grid_search': (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_knn8_grid_search_view': (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     'nerfail_gauss_weight': (c_i, [c_p, c_i64, c_i64, c_f, c_p, c_p]),
+    'nerfail_gauss_compose': (c_i, [c_p, c_p, c_i64, c_p, c_p]),
     'nerfail_gauss_fwd': (c_i, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p]),
     'nerfail_gauss_fwd_views': (c_i, [c_p, c_i64, c_p, c_i, c_i64, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -285,9 +285,33 @@ static int launch_fwd_views(const float4* spatial, long Ns, const FwdViews& tab,
     return NERFAIL_OK;
 }
 
+// ------------------------------------------------------------------------------------------ gauss_get_img (GN:309-319)
+// x_rgb = ori_rgb + r_rgb * (r_a / 255) where ori_a > 0 else 0, x_a = ori_a: the composite of K10 WITHOUT the epsilon clip and
+// WITHOUT the [0, 255] clip (gauss_get_img has neither), on an already gathered r. Streaming, 48 B per pixel.
+__global__ __launch_bounds__(256) void gauss_compose_kernel(const float4* __restrict__ ori, const float4* __restrict__ r, long n,
+                                                            float4* __restrict__ x_rgba) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const float4 o = ori[g], v = r[g];
+    const float alpha = __fdiv_rn(v.w, 255.0f);
+    const bool opaque = o.w > 0.f;
+    x_rgba[g] = make_float4(opaque ? __fadd_rn(o.x, __fmul_rn(v.x, alpha)) : 0.f, opaque ? __fadd_rn(o.y, __fmul_rn(v.y, alpha)) : 0.f,
+                            opaque ? __fadd_rn(o.z, __fmul_rn(v.z, alpha)) : 0.f, o.w);
+}
+
 }  // namespace nerfail
 
 using namespace nerfail;
+
+extern "C" int nerfail_gauss_compose(const float* ori_img, const float* r, int64_t n_pixels, float* x_rgba, void* stream) {
+    NF_REQUIRE(n_pixels >= 0, "n_pixels is negative");
+    if (n_pixels == 0) return NERFAIL_OK;
+    NF_REQUIRE(ori_img != nullptr && r != nullptr && x_rgba != nullptr, "NULL pointer");
+    gauss_compose_kernel<<<dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        (const float4*)ori_img, (const float4*)r, n_pixels, (float4*)x_rgba);
+    NF_LAUNCHED("gauss_compose_kernel");
+    return NERFAIL_OK;
+}
 
 extern "C" int nerfail_gauss_weight(const float* dist_and_index, int64_t B, int64_t P, float c, float* out, void* stream) {
     NF_REQUIRE(B >= 0 && P >= 0, "negative size");

@@ -231,7 +231,17 @@ __device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook
             // interval that ends inside this part holds exactly 4 * (quads per group) of them. They may therefore stay in
             // flight across the boundary together with the youngest group - otherwise every boundary would wait for
             // stores issued ~1.7 us earlier to be acknowledged.
-            constexpr int EXTRA = std::is_same<TStore, NoStore>::value ? 0 : 4 * (C::GP / OT);
+            // Counting them: the vm operations younger than the group a boundary waits for are the refill DMAs of
+            // the youngest group (GPW, issued behind the first MFMAs of the SYNC step that crossed the previous boundary) plus the
+            // stores of the steps from that SYNC step up to this boundary. SPQ == 2 (W = 256 full-width layers): the SYNC step is
+            // the store-less second step of a quad, the GP/OT quads in between each carry 4 stores on their first step -> 4*GP/OT
+            // whatever part came before. SPQ == 1 (W <= 128, and the W/2-wide views part at W = 256): every step carries stores,
+            // also the SYNC step itself - which belongs to the PREVIOUS part at a part's first boundary, and that part may be a
+            // store-less encoding part (or the store-less second step of a full-width quad): only GP/OT - 1 quads of stores are
+            // guaranteed. One quad fewer is allowed to stay in flight there (4 stores issued ~3 steps earlier must have been
+            // acknowledged - free in practice), so that never a DMA of the group about to be read is still outstanding.
+            constexpr int EXTRA = std::is_same<TStore, NoStore>::value ? 0 : 4 * (C::GP / OT - (SPQ == 1 ? 1 : 0));
+            static_assert(EXTRA >= 0, "a store-carrying part spans at least one quad per group");
             if (done % C::GP == 0) st.template step<HSP, true, EXTRA>(pr, mid, mf, post);
             else st.template step<HSP, false>(pr, mid, mf, post);
         }

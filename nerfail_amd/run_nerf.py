@@ -379,7 +379,8 @@ def _render_rays_pipeline(rays, network_fn, network_fine, user_query, N_samples,
 
     z_vals = torch.empty((R, N_samples), dtype=torch.float32, device=dev)
     pts = torch.empty((R, N_samples, 3), dtype=torch.float32, device=dev) if wants_pts(network_fn) else None
-    _lib.check(lib.nerfail_sample_coarse(_lib.dev(rays), R, _lib.dev(linspace01(N_samples, dev)), int(N_samples),
+    t_lin = linspace01(N_samples, dev)      # (cached per device; bound to a name so that the pointer below is never a temporary's)
+    _lib.check(lib.nerfail_sample_coarse(_lib.dev(rays), R, _lib.dev(t_lin), int(N_samples),
                                          _lib.dev(t_rand, 't_rand'), int(bool(lindisp)), _lib.dev(z_vals), _lib.dev(pts), st))
     raw, acts = query(pts, z_vals, network_fn)
     last_pass = not (N_importance > 0)

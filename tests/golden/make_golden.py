@@ -295,9 +295,28 @@ def g7():
         out.update({tag + '_rays': rays, tag + '_t_rand': t_rand.numpy(), tag + '_u': u.numpy(),
                     tag + '_target': target.numpy(), tag + '_loss': loss.item(),
                     tag + '_rgb_map': r['rgb_map'].detach().numpy()})
-        for nm, net in (('coarse', coarse), ('fine', fine)):
+        # Round 4: the SAME step of the reference in float64 - same rays, same draws, same weights. The
+        # per-parameter L2 distance between its fp32 and fp64 gradients is the reference's own rounding spread on this step
+        # (ReLU kinks and importance-sample bins that flip included); the HIP step is held to 2 x that, per parameter.
+        c64, f64 = make_net(D, W, 31).double(), make_net(D, W, 32).double()
+        torch.rand = FixedRand([t_rand.double(), u.double()])
+        try:
+            r64 = RN.render_rays(T(rays).double(), c64, query, 64, retraw=True, N_importance=128,
+                                 network_fine=f64, white_bkgd=True, perturb=1.)
+        finally:
+            torch.rand = orig
+        assert r64['rgb_map'].dtype == torch.float64
+        loss64 = RH.img2mse(r64['rgb_map'], target.double()) + RH.img2mse(r64['rgb0'], target.double())
+        loss64.backward()
+        out[tag + '_loss64'] = loss64.item()
+        for nm, net, n64 in (('coarse', coarse, c64), ('fine', fine, f64)):
+            g64s = dict((k, p.grad.numpy()) for k, p in n64.named_parameters())
             for k, p in net.named_parameters():
                 gr = p.grad.numpy()
+                g64 = g64s[k]
+                e = float(np.linalg.norm(gr.astype(np.float64) - g64) / max(np.linalg.norm(g64), 1e-300))
+                out['%s_%s_referr_%s' % (tag, nm, k)] = e
+                print('  g7 %-5s %-6s %-26s |g| %.3e  reference fp32-vs-fp64 L2 err %.2e' % (tag, nm, k, np.linalg.norm(g64), e))
                 # store full small grads; for the big net keep norms + a slice to stay small
                 if tag == 'small':
                     out['%s_%s_grad_%s' % (tag, nm, k)] = gr
@@ -760,6 +779,8 @@ def g19():
         'nerf_to_coord.render_rays': sig(NC.render_rays), 'nerf_to_coord.render_path': sig(NC.render_path),
         'GaussNet.gauss_net.__init__': sig(GN.gauss_net.__init__), 'GaussNet.gauss_net.forward': sig(GN.gauss_net.forward),
         'GaussNet.create_gauss_w.__init__': sig(GN.create_gauss_w.__init__), 'GaussNet.create_gauss_w.forward': sig(GN.create_gauss_w.forward),
+        'GaussNet.gauss_get_r.__init__': sig(GN.gauss_get_r.__init__), 'GaussNet.gauss_get_r.forward': sig(GN.gauss_get_r.forward),
+        'GaussNet.gauss_get_img.__init__': sig(GN.gauss_get_img.__init__), 'GaussNet.gauss_get_img.forward': sig(GN.gauss_get_img.forward),
         'deepfool.deepfool': sig(DF.deepfool), 'load_blender.load_blender_data': sig(LB.load_blender_data),
         'load_blender.pose_spherical': sig(LB.pose_spherical),
     }
@@ -768,8 +789,55 @@ def g19():
     print('%-28s %8.1f KB' % ('g19_signatures.json', os.path.getsize(path) / 1024))
 
 
+# ---------------------------------------------------------------- G20 gauss_get_r / gauss_get_img (GN:189-337)
+def g20():
+    """gauss_get_r.forward (weights from RAW distances, GN:224-268) and the hot part of gauss_get_img.forward (GN:309-319)
+    run on the g10-style inputs; the classifier tail of gauss_get_img goes through torchvision's Resize (absent here), so
+    only `r` and `x_rgba` - what the path computes - are stored, plus gauss_get_r's epsilon bookkeeping."""
+    rs = np.random.RandomState(20)
+    P, B, H, W = 3, 2, 32, 32
+    s = rs.uniform(-40, 40, size=(P, H, W, 4)).astype(np.float32)
+    s[..., 3] = np.where(rs.uniform(size=(P, H, W)) < 0.8, 255.0, 0.0).astype(np.float32)
+    ori = synth.disc_alpha_image(B, H, W, seed=21)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    dist[0, 0, 0] = 5.0                   # sum of the Gaussians underflows to 0 -> the where(ds > 0, ., 0) branch
+    dist[0, 0, 1] = 0.0                   # exact hits
+    idx = rs.randint(0, P * H * W, size=(B, H, W, 8)).astype(np.float32)
+    idx[0, 1, 0, :] = 7.0
+    dai = np.stack([dist, idx], 1)
+    get_r = GN.gauss_get_r('cpu', 0.02, _PoolCls(), 'my_model')
+    with torch.no_grad():
+        r = get_r(T(s), T(dai))
+    out = dict(s=s, ori=ori, dist_and_index=dai, r=r.numpy(), eps3d_max=get_r.epsilon_3d_max, eps3d_min=get_r.epsilon_3d_min)
+
+    class _Stop(Exception):
+        pass
+
+    class _Grab(torch.nn.Module):        # the first thing the classifier tail touches after x_rgba exists is Resize: stop there
+        def forward(self, x):
+            raise _Stop()
+    get_img = GN.gauss_get_img('cpu', 0.02, _PoolCls(), 'my_model')
+    # x_rgba is a local of forward(); take it from the frame when the tail reaches the (absent) Resize
+    get_img.torch_resize_299 = _Grab()
+    try:
+        with torch.no_grad():
+            get_img(T(ori), r)
+        raise AssertionError('the Resize stand-in was not reached')
+    except _Stop:
+        import traceback
+        tb = sys.exc_info()[2]
+        while tb.tb_next is not None and 'x_rgba' not in tb.tb_frame.f_locals:
+            tb = tb.tb_next
+        frame = tb.tb_frame
+        while 'x_rgba' not in frame.f_locals:
+            tb = tb.tb_next
+            frame = tb.tb_frame
+        out['x_rgba'] = frame.f_locals['x_rgba'].detach().numpy()
+    save('g20_gauss_get', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20']
     for w in which:
         globals()[w]()
 

@@ -23,6 +23,51 @@ def test_create_gauss_w(golden):
     assert (N(i_w)[0, 0, 0, 0] == 0).all()
 
 
+def test_gauss_get_r_and_gauss_get_img(golden):
+    """GN:189-337: `from model.GaussNet import gauss_net, gauss_get_r, gauss_get_img` (attack_NeRFail.py:23)
+    works against the mirror; outputs vs fixture g20 (the reference run) and vs the oracle, gradients vs torch autograd of the
+    same formulas."""
+    from nerfail_amd.GaussNet import gauss_net, gauss_get_r, gauss_get_img      # noqa: F401  (the reference's import line)
+    g = golden('g20_gauss_get')
+    w = T(golden('g10_gauss_net')['cls_w'])
+
+    class Cls(torch.nn.Module):
+        def forward(self, x):
+            return torch.nn.functional.adaptive_avg_pool2d(x, 4).reshape(x.shape[0], -1) @ w.t()
+    get_r = gauss_get_r(dev(), 0.02, Cls(), 'my_model')
+    s = T(g['s']).requires_grad_(True)
+    r = get_r(s, T(g['dist_and_index']))
+    assert rel_err(N(r), g['r']) < 1e-5
+    assert rel_err(N(r), OG.gauss_get_r(g['s'], g['dist_and_index'], 0.02)[0]) < 1e-5
+    assert (N(r)[0, 0, 0] == 0).all()
+    assert abs(get_r.epsilon_3d_max - float(g['eps3d_max'])) < 1e-3 * abs(float(g['eps3d_max']))
+    assert abs(get_r.epsilon_3d_min - float(g['eps3d_min'])) < 1e-3 * abs(float(g['eps3d_min']))
+    get_r.epsilon_3d_zero()
+    assert get_r.epsilon_3d_max == 0 and get_r.epsilon_3d_min == 0
+    # d r / d s: r is linear in s with the K9 weights as coefficients
+    Gx = T(np.random.RandomState(3).normal(size=g['r'].shape).astype(np.float32))
+    (r * Gx).sum().backward()
+    wi = OG.create_gauss_w(g['dist_and_index'], 0.02)[0]
+    ref = OG.gauss_backward(g['s'], wi, np.zeros_like(g['ori']), N(Gx), np.zeros_like(N(Gx)), None)
+    assert rel_err(N(s.grad), ref) < 1e-4
+
+    get_img = gauss_get_img(dev(), 0.02, Cls(), 'my_model')
+    rt = T(g['r']).requires_grad_(True)
+    r_out, x_rgba, cla, ori, ori_cla = get_img(T(g['ori']), rt)
+    assert r_out is rt
+    assert rel_err(N(x_rgba), g['x_rgba']) < 1e-6
+    assert np.array_equal(N(x_rgba), OG.gauss_get_img(g['ori'], g['r']))         # same three roundings
+    assert tuple(cla.shape) == (2, 8) and tuple(ori_cla.shape) == (2, 8) and torch.equal(ori, T(g['ori']))
+    # gradient of the composite w.r.t. r against torch autograd of GN:309-319
+    Gr = T(np.random.RandomState(4).normal(size=g['r'].shape).astype(np.float32))
+    (x_rgba * Gr).sum().backward()
+    r2 = T(g['r']).requires_grad_(True)
+    o = T(g['ori'])
+    x2 = torch.where(o[..., 3:4] > 0, o[..., :3] + r2[..., :3] * (r2[..., 3:4] / 255), torch.zeros_like(o[..., :3]))
+    (torch.cat([x2, o[..., 3:4]], -1) * Gr).sum().backward()
+    assert rel_err(N(rt.grad), N(r2.grad)) < 1e-5
+
+
 @pytest.mark.parametrize('det', [True, False])
 @pytest.mark.parametrize('tag,eps', [('epsNone_', None), ('eps32_', 32.0)])
 def test_gauss_forward_backward(golden, tag, eps, det):
@@ -474,6 +519,50 @@ def test_fingerprint_mixes_every_word_with_its_position():
         k = fp(other.reshape(base.shape))
         assert k == ref(other) and k not in seen
         seen.add(k)
+
+
+def test_resident_views_are_checked_against_passed_device_maps_and_logit_cache_follows_the_image(tmp_path):
+    """(i) a view that is resident under an id wins over the tensor passed under that id - but ONCE per id a
+    passed DEVICE map is compared with the resident one, so that a reused id / regenerated map raises instead of silently
+    differentiating through another view; (ii) register_view of a new image under an id invalidates the cached original-image
+    logits of that id; (iii) MyDataset view ids carry the files' (mtime, size)."""
+    from nerfail_amd import GaussNet as G, attack as A
+    from nerfail_amd.MyDataset import gauss_dataset
+    s0, wi, ori_u8, victim = _toy_attack(seed=55)
+    label = torch.tensor(2, device=dev())
+    Ns = s0.numel() // 4
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear(); G._VIEW_PASSED_OK.clear()
+    ids = [('scene', 'split', i) for i in range(wi.shape[0])]
+    for i, vid in enumerate(ids):
+        G.register_view(vid, Ns, weight_and_index=wi[i], ori_img=ori_u8[i])
+    net = G.gauss_net(dev(), 0.02, victim, 'my_model', epsilon=None)
+    net.cache_ori_cla = True
+    ori_dev = torch.from_numpy(ori_u8).to(dev())
+    ref, _ = A.nerfail_s_step(net, s0, s0, wi, ori_dev, label, 2.0, 32.0, False, view_ids=ids)      # same maps passed: accepted
+    assert all(G._view_key(v, Ns) in G._VIEW_PASSED_OK for v in ids)
+    # (i) another scene's maps under the same ids, as a device tensor: caught on first sight
+    G._VIEW_PASSED_OK.clear()
+    with pytest.raises(ValueError, match='DIFFERENT map'):
+        A.nerfail_s_step(net, s0, s0, wi.flip(0).contiguous(), ori_dev, label, 2.0, 32.0, False, view_ids=ids)
+    # (ii) the image of view 0 is replaced: the step must see the new image's logits (cache keyed with the image epoch)
+    _, cla0, ori_cla0, _, _ = net.attack_forward(s0, None, None, view_ids=ids)
+    new_img = ori_u8[0].copy()
+    new_img[..., :3] = 255 - new_img[..., :3]
+    G.register_view(ids[0], Ns, ori_img=new_img)
+    _, cla1, ori_cla1, _, _ = net.attack_forward(s0, None, None, view_ids=ids)
+    fresh = G.gauss_net(dev(), 0.02, victim, 'my_model', epsilon=None)
+    _, _, ori_cla_ref, _, _ = fresh.attack_forward(s0, None, None, view_ids=ids)
+    assert not torch.equal(ori_cla1[0], ori_cla0[0]) and torch.equal(ori_cla1, ori_cla_ref)
+    # (iii) dataset ids change with the file
+    mp, ip = str(tmp_path / '0.pth'), str(tmp_path / '0.png')
+    torch.save(wi[0].cpu(), mp)
+    from PIL import Image
+    Image.fromarray(ori_u8[0][..., [2, 1, 0, 3]], 'RGBA').save(ip)
+    a = gauss_dataset([mp], [ip], [''], [''], dev(), Ns=Ns).view_id(0)
+    os.utime(mp, ns=(5, 5))
+    b = gauss_dataset([mp], [ip], [''], [''], dev(), Ns=Ns).view_id(0)
+    assert a != b and a[0] == b[0] == os.path.abspath(mp)
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear(); G._VIEW_PASSED_OK.clear()
 
 
 def test_view_ids_are_checked_and_stale_sidecars_are_rebuilt(tmp_path):

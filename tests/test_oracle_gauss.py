@@ -24,6 +24,18 @@ def test_gauss_forward_matches_reference(golden):
         assert abs(emin - float(g[tag + 'eps3d_min'])) < 1e-3 * abs(emin)
 
 
+def test_gauss_get_r_and_get_img_match_reference(golden):
+    """g20: the reference's gauss_get_r.forward (GN:224-268) and the hot part of gauss_get_img.forward (GN:309-319)."""
+    g = golden('g20_gauss_get')
+    r, (emax, emin) = O.gauss_get_r(g['s'], g['dist_and_index'], c=0.02)
+    assert rel_err(r, g['r']) < 1e-5
+    assert (r[0, 0, 0] == 0).all()                            # sum g underflow -> 0 branch (GN:245)
+    assert abs(emax - float(g['eps3d_max'])) < 1e-3 * abs(emax) and abs(emin - float(g['eps3d_min'])) < 1e-3 * abs(emin)
+    x_rgba = O.gauss_get_img(g['ori'], g['r'])
+    assert rel_err(x_rgba, g['x_rgba']) < 1e-6
+    assert float(np.abs(x_rgba).max()) > 255.0 or float(x_rgba.min()) < 0.0     # the fixture exercises "no [0,255] clip"
+
+
 def test_gauss_backward_matches_reference_autograd(golden):
     g = golden('g10_gauss_net')
     for tag, eps in (('epsNone_', None), ('eps32_', 32.0)):
