@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256) void gauss_pixel_grad_kernel(const float4* __r
 // pass 1, rgb-gradient-only form (the NeRFail-S step: AS:357-392 never reads the alpha channel's gradient): from what the
 // forward left behind - alpha and the 3-bit pass mask, 5 bytes per pixel - instead of x and ori (32 bytes). Pixels whose
 // mask is 0 (background, saturated) read nothing else. The rgb values equal gauss_pixel_grad_kernel's bit for bit.
+// (Round 4 measured the alternative the round-3 verdict asked for - forming this at the gather inside the reduce, no g_pix
+// round trip: three gathers per entry instead of one, reduce 98 -> 143 us for the 25 us this pass takes. Kept as a pass.)
 __global__ __launch_bounds__(256) void gauss_pixel_grad_rgb_kernel(const float* __restrict__ aux_alpha,
                                                                    const unsigned char* __restrict__ aux_mask,
                                                                    const float4* __restrict__ grad_x_rgba, long n,
@@ -132,45 +134,185 @@ __device__ __forceinline__ float4 f4_add(const float4& a, const float4& b) { ret
 
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
-// One step of the segmented scan: every lane looks at the lane the DPP control names (a lane without a source - row
-// start, masked row - sees key -2, which no entry has) and adds that lane's sums if it holds the same key.
-template <int CTRL, int ROW_MASK = 0xF, bool W4 = true, int C>
-__device__ __forceinline__ void seg_scan_step(const int key, float4 (&v)[C]) {
-    const int key_src = __builtin_amdgcn_update_dpp(-2, key, CTRL, ROW_MASK, 0xF, false);
-    const bool same = key_src == key;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const float ax = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].x), CTRL, ROW_MASK, 0xF, false));
-        const float ay = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].y), CTRL, ROW_MASK, 0xF, false));
-        const float az = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].z), CTRL, ROW_MASK, 0xF, false));
-        if (same) { v[c].x += ax; v[c].y += ay; v[c].z += az; }
-        if constexpr (W4) {                                             // (the rgb-only step path carries no fourth channel)
-            const float aw = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c].w), CTRL, ROW_MASK, 0xF, false));
-            if (same) v[c].w += aw;
-        }
-    }
-}
-
 // The work of one wave = one chunk `wg` of an index with E entries. key_of[e] names the destination of entry e (equal
 // for the entries of one row, entries sorted by it): a row id when `out` is the dense table (stride = Ns), a row ORDINAL
 // when `out` is a view's compact row-sum array (stride = its row count; nerfail_gauss_bwd_views).
 // PACKED = a per-view index in its compact form (nerfail_gauss_view_pack): `contrib` holds pixel * 2 + (1 if the entry
 // starts a row), `row_of` holds ONE int per chunk (the ordinal of the row the chunk's first entry belongs to), and an
-// entry's key - its row's ordinal - is that plus the number of row starts up to the entry (a ballot and a bit count per
-// 64 entries): 8 bytes per entry instead of 12.
+// entry's key - its row's ordinal - is that plus the number of row starts up to the entry: 8 bytes per entry instead of 12.
+//
+// Round 4: a lane owns 8 CONSECUTIVE entries. Round 3 gave lane l the entries l, l + 64, ... and ran a 6-step wave-wide
+// segmented scan for every 64 entries: 1 070 vector instructions per wave and chunk, 59 M per 8-view batch - on 16-lane
+// SIMDs (a wave64 instruction takes 4 cycles) that alone is 96 of the kernel's 99.6 us (SQ_INSTS_VALU, SQ_WAIT_INST_ANY =
+// 42 % of the wave cycles, profiles/r04_k11_counters.txt): the kernel was bound by vector-instruction issue, not by memory.
+// Now each lane adds up the runs inside its own 8 entries serially (packed fp32 adds, no cross-lane traffic) and writes the
+// rows that begin AND end there directly; what crosses lanes - the run still open at a lane's end, continued through lanes
+// without a row start, closed by the first start of a later lane - is ONE segmented scan per 512 entries instead of eight.
+// Index and weight loads are two 16-byte loads per lane and array (a wave covers 2 KB contiguous per array).
+// Every order is fixed (inside a lane left to right, lanes combined by the scan's fixed tree, chunks by
+// seg_combine_chunk in chunk order): bitwise reproducible, no atomics, and identical for 1 and for C right-hand sides.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct V4 { f32x2 lo, hi; };                   // (x, y), (z, w): the sums run on v_pk_add_f32 / v_pk_mul_f32 (same rounding)
+
+__device__ __forceinline__ float4 v4_f4(const V4& v) { return make_float4(v.lo.x, v.lo.y, v.hi.x, v.hi.y); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+
+// inclusive prefix sum of one int per lane over the 64 lanes (row_shr 1 2 4 8, then the last lane of a row into the rows behind)
+__device__ __forceinline__ int wave_incl_sum(int x) {
+    x += dpp_i0<0x111, 0xF>(x);
+    x += dpp_i0<0x112, 0xF>(x);
+    x += dpp_i0<0x114, 0xF>(x);
+    x += dpp_i0<0x118, 0xF>(x);
+    x += dpp_i0<0x142, 0xA>(x);
+    x += dpp_i0<0x143, 0xC>(x);
+    return x;
+}
+
+// One step of the segmented scan: every lane looks at the lane the DPP control names (a lane without a source - row
+// start, masked row - sees key -2, which no entry has) and adds that lane's sums if it holds the same key.
+template <int CTRL, int ROW_MASK, bool W4, int C>
+__device__ __forceinline__ void seg_scan_step(const int key, V4 (&v)[C]) {
+    const int key_src = __builtin_amdgcn_update_dpp(-2, key, CTRL, ROW_MASK, 0xF, false);
+    const bool same = key_src == key;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        V4 a;
+        a.lo.x = __int_as_float(dpp_i0<CTRL, ROW_MASK>(__float_as_int(v[c].lo.x)));
+        a.lo.y = __int_as_float(dpp_i0<CTRL, ROW_MASK>(__float_as_int(v[c].lo.y)));
+        a.hi.x = __int_as_float(dpp_i0<CTRL, ROW_MASK>(__float_as_int(v[c].hi.x)));
+        a.hi.y = W4 ? __int_as_float(dpp_i0<CTRL, ROW_MASK>(__float_as_int(v[c].hi.y))) : 0.f;   // (the rgb-only step path carries no fourth channel)
+        if (same) { v[c].lo += a.lo; v[c].hi += a.hi; }
+    }
+}
+
+// The state of one lane while it walks its 8 entries left to right.
+template <int C>
+struct SegLane {
+    V4 acc[C];                                  // the run that is open
+    V4 H[C];                                    // the part of the ENTERING run (open when the lane begins) that lies in this lane
+    bool seen;                                  // a row started in this lane
+    int key;                                    // destination of the open run
+    __device__ __forceinline__ void init(int kin) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { acc[c].lo = acc[c].hi = (f32x2){0.f, 0.f}; H[c] = acc[c]; }
+        seen = false;
+        key = kin;
+    }
+    // entry with product p; s: it begins a row; key_after: its destination
+    template <class Emit>
+    __device__ __forceinline__ void entry(const bool s, const int key_after, const V4 (&p)[C], Emit& emit) {
+        if (s) {                                                       // the run open so far ends in front of this entry
+            if (!seen) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) H[c] = acc[c];             // the entering run: finished in seg_finish, with the lanes before
+            } else emit(key, acc);                                     // began in this lane: complete
+        }
+        key = key_after;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const f32x2 lo = acc[c].lo + p[c].lo, hi = acc[c].hi + p[c].hi;
+            acc[c].lo = s ? p[c].lo : lo;
+            acc[c].hi = s ? p[c].hi : hi;
+        }
+        seen = seen || s;
+    }
+};
+
+// After the lanes' own passes: the runs that cross lanes, the chunk's records. Returns the key of the run open at the chunk's
+// end (wave-uniform) and whether that run was emitted as a complete row.
+template <int C, bool W4, class Emit>
+__device__ __forceinline__ int seg_finish(SegLane<C>& st, const int lane, const long wg, const int kin, const bool first_entry_starts,
+                                          const int first_row, const bool head_partial, const bool tail_complete,
+                                          int* __restrict__ rec_row, float4* __restrict__ rec_val, Emit& emit, bool& tail_emitted) {
+    // inclusive segmented scan of the runs still open at the lanes' ends, keyed by the lanes' last keys (equal over a stretch
+    // of lanes <=> no row starts in the later ones): Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the
+    // last lane of a row handed to the next rows (row_bcast:15 / :31) - if that lane's key is mine, everything between it and
+    // me has that key too, so its sum is exactly what my run is missing. (__shfl_up is ds_bpermute_b32 on gfx9: DPP moves
+    // stay in the vector registers.)
+    seg_scan_step<0x111, 0xF, W4>(st.key, st.acc);
+    seg_scan_step<0x112, 0xF, W4>(st.key, st.acc);
+    seg_scan_step<0x114, 0xF, W4>(st.key, st.acc);
+    seg_scan_step<0x118, 0xF, W4>(st.key, st.acc);
+    seg_scan_step<0x142, 0xA, W4>(st.key, st.acc);
+    seg_scan_step<0x143, 0xC, W4>(st.key, st.acc);
+    // the entering run of a lane with a start ends there: (sum over the lanes before = the previous lane's scan value) + H
+    {
+        V4 tot[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {                                  // wave_shr:1 - lane l receives lane l - 1 (lane 0: nothing, 0)
+            V4 x;
+            x.lo.x = __int_as_float(dpp_i0<0x138, 0xF>(__float_as_int(st.acc[c].lo.x)));
+            x.lo.y = __int_as_float(dpp_i0<0x138, 0xF>(__float_as_int(st.acc[c].lo.y)));
+            x.hi.x = __int_as_float(dpp_i0<0x138, 0xF>(__float_as_int(st.acc[c].hi.x)));
+            x.hi.y = W4 ? __int_as_float(dpp_i0<0x138, 0xF>(__float_as_int(st.acc[c].hi.y))) : 0.f;
+            tot[c].lo = x.lo + st.H[c].lo;
+            tot[c].hi = x.hi + st.H[c].hi;
+        }
+        const bool entering = lane != 0 || !first_entry_starts;        // (the chunk's first entry starting a row closes nothing)
+        if (st.seen && entering) {
+            if (kin == first_row && head_partial) {                    // began in an earlier chunk: partial (head) record
+                rec_row[4 * wg] = kin;
+#pragma unroll
+                for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = v4_f4(tot[c]);
+            } else emit(kin, tot);
+        }
+    }
+    // the run still open at the end of the chunk
+    const int carry_row = __builtin_amdgcn_readlane(st.key, 63);
+    V4 carry[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        carry[c].lo = (f32x2){lane63(st.acc[c].lo.x), lane63(st.acc[c].lo.y)};
+        carry[c].hi = (f32x2){lane63(st.acc[c].hi.x), W4 ? lane63(st.acc[c].hi.y) : 0.f};
+    }
+    const bool is_head = carry_row == first_row && head_partial;
+    tail_emitted = tail_complete && !is_head;
+    if (lane == 0) {
+        if (tail_emitted) emit(carry_row, carry);
+        else if (tail_complete) {                                      // ends here, began earlier
+            rec_row[4 * wg] = carry_row;
+#pragma unroll
+            for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = v4_f4(carry[c]);
+        } else {                                                       // continues in the next chunk
+            rec_row[4 * wg + 1] = carry_row;
+            rec_row[4 * wg + 2] = is_head ? 0 : 1;                     // 1: the row STARTS in this chunk
+#pragma unroll
+            for (int c = 0; c < C; ++c) rec_val[(2 * wg + 1) * C + c] = v4_f4(carry[c]);
+        }
+    }
+    return carry_row;
+}
+
+// L (optional, C == 1 and PACKED only): this wave's LDS slice of kSegLdsSlots float4. With it, a FULL chunk takes the
+// transposed route: index / weight loads and gathers in the entry-strided pattern (lane l: entries l, l + 64, ... - adjacent
+// lanes read adjacent entries, whose pixels share 128-byte lines: ~15 lines per gather instruction instead of ~64 when a lane
+// gathers for its own 8 consecutive entries, and the vector-memory pipe processes an instruction line by line), products
+// w * g written to LDS entry-major (entry e in slot e ^ ((e >> 3) & 7): a permutation inside every aligned group of 8 slots,
+// so the writes stay conflict-free and the read-back - lane l reads slots 8 l + (k ^ (l & 7)) - spreads 8 lanes over all 32
+// banks; exactly 8 KB per wave = 5 workgroups per CU) and read back lane-consecutive; complete rows are collected in the same slice by ordinal and leave as one contiguous run of
+// full 16-byte-per-lane stores. Same products, same order of additions: the bits equal the direct route's.
+constexpr int kSegLdsSlots = kSegChunk;
+#ifndef NF_SEG_LDS_MULT
+#define NF_SEG_LDS_MULT 1      // (occupancy experiment: 2 halves the waves per CU)
+#endif
+
 template <int C, bool PACKED, bool W4 = true>
 __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, const long E, const int* __restrict__ row_of,
                                                  const int* __restrict__ contrib, const float* __restrict__ w_sorted,
                                                  const float4* __restrict__ g_pix, const int accumulate,
                                                  float4* __restrict__ grad_spatial, const long Ns,
-                                                 int* __restrict__ rec_row, float4* __restrict__ rec_val) {
-    // UB: steps whose gathers are issued together (register budget: UB * C float4 per lane)
+                                                 int* __restrict__ rec_row, float4* __restrict__ rec_val, float4* L = nullptr) {
+    // UB: entries of a lane whose gathers are issued together (register budget: UB * C float4 per lane)
     constexpr int UB = C == 1 ? 8 : (C == 2 ? 4 : (C <= 4 ? 2 : 1));
+    static_assert(kSegU == 8, "a lane owns 8 consecutive entries: two 16-byte loads per array");
     const long base = wg * kSegChunk;
     // record slots of this chunk: [4*wg] head row, [4*wg+1] tail row, [4*wg+2] tail-starts-here flag
     if (lane == 0) { rec_row[4 * wg] = kSegNone; rec_row[4 * wg + 1] = kSegNone; rec_row[4 * wg + 2] = 0; }
     if (base >= E) return;                                             // wave-uniform
     const long end = base + kSegChunk < E ? base + kSegChunk : E;
+    const bool full = end - base == kSegChunk;                         // wave-uniform: every chunk of a view but its last
     int first_row;
     bool head_partial;                                                 // the chunk's first row began in an earlier chunk
     bool tail_complete;                                                // the row of the chunk's last entry ends with it
@@ -183,123 +325,150 @@ __device__ __forceinline__ void seg_reduce_chunk(const long wg, const int lane, 
         head_partial = base > 0 && row_of[base - 1] == first_row;
         tail_complete = end >= E || row_of[end] != row_of[end - 1];
     }
-    int running = first_row;                                           // PACKED: key of the last entry handled so far
-    int carry_row = kSegNone;
-    float4 carry[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) carry[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long e0 = base + (long)lane * kSegU;                         // this lane's first entry
+    SegLane<C> st;
 
-    auto emit = [&](int row, const float4 (&v)[C], bool owner) {       // a row whose sum is complete inside this chunk
-        if (!owner) return;
+    if constexpr (C == 1 && PACKED) {
+        if (L != nullptr && full) {
+            // ---- A: entry-strided loads, gathers and products -> LDS
+            int ids[kSegU];
+            float ws[kSegU];
+#pragma unroll
+            for (int u = 0; u < kSegU; ++u) { ids[u] = contrib[base + u * 64 + lane]; ws[u] = w_sorted[base + u * 64 + lane]; }
+            __builtin_amdgcn_sched_barrier(0);
+            float4 g[kSegU];
+#pragma unroll
+            for (int u = 0; u < kSegU; ++u) g[u] = g_pix[ids[u] >> 1];
+            // the lane's own 8 consecutive index words (start flags): the lines were just loaded above
+            const int4 ia = *reinterpret_cast<const int4*>(contrib + e0), ib = *reinterpret_cast<const int4*>(contrib + e0 + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            float4* const Lw = L + (lane ^ ((lane >> 3) & 7));
+#pragma unroll
+            for (int u = 0; u < kSegU; ++u) {
+                const f32x2 w2 = {ws[u], ws[u]};
+                const f32x2 lo = w2 * (f32x2){g[u].x, g[u].y}, hi = w2 * (f32x2){g[u].z, W4 ? g[u].w : 0.f};
+                Lw[64 * u] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            const unsigned starts = (unsigned)(ia.x & 1) | (unsigned)(ia.y & 1) << 1 | (unsigned)(ia.z & 1) << 2 | (unsigned)(ia.w & 1) << 3 |
+                                    (unsigned)(ib.x & 1) << 4 | (unsigned)(ib.y & 1) << 5 | (unsigned)(ib.z & 1) << 6 | (unsigned)(ib.w & 1) << 7;
+            const unsigned counted = lane == 0 ? (starts & ~1u) : starts;
+            const int ns = __popc(counted);
+            const int kin = first_row + wave_incl_sum(ns) - ns;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (one wave: its LDS operations execute in order)
+            // ---- B: the lane's 8 consecutive products back from LDS, then its own pass; rows collected in LDS by ordinal
+            float4 pk[kSegU];
+            const float4* const Lr = L + 8 * lane;
+#pragma unroll
+            for (int k = 0; k < kSegU; ++k) pk[k] = Lr[k ^ (lane & 7)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            auto emit = [&](int row, const V4 (&v)[1]) { L[row - first_row] = v4_f4(v[0]); };
+            st.init(kin);
+#pragma unroll
+            for (int k = 0; k < kSegU; ++k) {
+                const bool s = (starts >> k) & 1u;
+                V4 p[1];
+                p[0].lo = (f32x2){pk[k].x, pk[k].y};
+                p[0].hi = (f32x2){pk[k].z, pk[k].w};
+                st.entry(s, st.key + ((counted >> k) & 1u), p, emit);
+            }
+            bool tail_emitted;
+            const int carry_row = seg_finish<1, W4>(st, lane, wg, kin, (starts & 1u) != 0u, first_row, head_partial, tail_complete,
+                                                    rec_row, rec_val, emit, tail_emitted);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- C: every row between the chunk's first (if it began here) and its last (if it ends here) is complete
+            const int lo_key = first_row + (head_partial ? 1 : 0);
+            const int hi_key = tail_emitted ? carry_row : carry_row - 1;
+            for (int r = lo_key + lane; r <= hi_key; r += 64) grad_spatial[r] = L[r - first_row];
+            return;
+        }
+    }
+
+    // ---- direct route: this lane's 8 entries straight from the arrays (a partial last chunk repeats its last entry and masks
+    // the repeats out)
+    int id[kSegU], rk[kSegU];
+    float w[kSegU];
+    unsigned valid = 0xffu;
+    if (full) {
+        const int4 ia = *reinterpret_cast<const int4*>(contrib + e0), ib = *reinterpret_cast<const int4*>(contrib + e0 + 4);
+        const float4 wa = *reinterpret_cast<const float4*>(w_sorted + e0), wb = *reinterpret_cast<const float4*>(w_sorted + e0 + 4);
+        id[0] = ia.x; id[1] = ia.y; id[2] = ia.z; id[3] = ia.w; id[4] = ib.x; id[5] = ib.y; id[6] = ib.z; id[7] = ib.w;
+        w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w; w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+        if constexpr (!PACKED) {
+            const int4 ra = *reinterpret_cast<const int4*>(row_of + e0), rb = *reinterpret_cast<const int4*>(row_of + e0 + 4);
+            rk[0] = ra.x; rk[1] = ra.y; rk[2] = ra.z; rk[3] = ra.w; rk[4] = rb.x; rk[5] = rb.y; rk[6] = rb.z; rk[7] = rb.w;
+        }
+    } else {
+        valid = 0u;
+#pragma unroll
+        for (int k = 0; k < kSegU; ++k) {                              // (clamped: unconditional loads)
+            const long i = e0 + k;
+            const long ic = i < end ? i : end - 1;
+            id[k] = contrib[ic];
+            w[k] = w_sorted[ic];
+            if constexpr (!PACKED) rk[k] = row_of[ic];
+            valid |= (i < end ? 1u : 0u) << k;
+        }
+    }
+    // bit k of `starts`: entry k begins a row. The key (destination) of entry k: PACKED - the ordinal first_row + the number
+    // of starts among the chunk's entries 1 .. k (the chunk's own first entry does not count: first_row is ITS row);
+    // otherwise the row id itself. `kin` = the key of the run that is open when the lane begins (= the previous lane's last key).
+    unsigned starts = 0u, counted = 0u;
+    int kin;
+    if constexpr (PACKED) {
+#pragma unroll
+        for (int k = 0; k < kSegU; ++k) starts |= (unsigned)(id[k] & 1) << k;
+        starts &= valid;
+        counted = lane == 0 ? (starts & ~1u) : starts;
+        const int ns = __popc(counted);
+        kin = first_row + wave_incl_sum(ns) - ns;
+    } else {
+        const long ep = (e0 < end ? e0 : end) - 1;                     // the entry before this lane's first (>= base - 1)
+        const int prev = ep >= 0 ? row_of[ep] : -1;
+        kin = lane == 0 ? first_row : prev;
+        starts = (lane == 0 ? (head_partial ? 0u : 1u) : (rk[0] != prev ? 1u : 0u));
+#pragma unroll
+        for (int k = 1; k < kSegU; ++k) starts |= (rk[k] != rk[k - 1] ? 1u : 0u) << k;
+        starts &= valid;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto emit = [&](int row, const V4 (&v)[C]) {                       // a row whose sum is complete inside this chunk
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            float4 o = v[c];
+            float4 o = v4_f4(v[c]);
             if (accumulate) o = f4_add(grad_spatial[(long)c * Ns + row], o);
             grad_spatial[(long)c * Ns + row] = o;
         }
     };
-
-#pragma unroll 1
-    for (int u0 = 0; u0 < kSegU; u0 += UB) {
-        if (base + (long)u0 * 64 >= end) break;                        // wave-uniform
-        int key[UB], id[UB];
-        float w[UB];
+    st.init(kin);
+#pragma unroll
+    for (int k0 = 0; k0 < kSegU; k0 += UB) {
         float4 g[UB][C];
-        // all index loads of the batch first, then all gathers: UB * C independent 16-byte gathers in flight. (Left to
-        // itself the compiler interleaves "load contrib[u]; s_waitcnt vmcnt(0); gather" per u - 2 * UB memory round
-        // trips in a chain, each wait also draining the gather before it; the sched_barriers pin the two phases.)
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {                                 // (clamped: unconditional loads)
-            const long i = base + (long)(u0 + u) * 64 + lane;
-            const long ic = i < end ? i : end - 1;
-            id[u] = contrib[ic];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const long i = base + (long)(u0 + u) * 64 + lane;
-            const bool ok = i < end;
-            const long ic = ok ? i : end - 1;
-            if constexpr (PACKED) key[u] = ok ? 0 : kSegNone;          // (the ordinal is counted below, step by step)
-            else key[u] = ok ? row_of[ic] : kSegNone;
-            w[u] = ok ? w_sorted[ic] : 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // all gathers of the batch first: UB * C independent 16-byte gathers in flight (the sched_barriers pin the phases;
+        // left to itself the compiler chains "gather; s_waitcnt vmcnt(0); use" per entry)
 #pragma unroll
         for (int u = 0; u < UB; ++u)
 #pragma unroll
-            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> (PACKED ? 1 : 3)) * C + c];
+            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[k0 + u] >> (PACKED ? 1 : 3)) * C + c];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            if (base + (long)(u0 + u) * 64 >= end) break;              // wave-uniform
-            if constexpr (PACKED) {
-                // row starts among these 64 entries (the chunk's very first entry does not count: first_row is ITS row)
-                const bool st = key[u] != kSegNone && (id[u] & 1) != 0 && !(u0 + u == 0 && lane == 0);
-                const unsigned long long m = __ballot(st);
-                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (key[u] != kSegNone) key[u] = running + below + (st ? 1 : 0);
-                running += __popcll(m);
+            const int k = k0 + u;
+            const bool s = (starts >> k) & 1u;
+            V4 p[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const f32x2 w2 = {w[k], w[k]};
+                p[c].lo = w2 * (f32x2){g[u][c].x, g[u][c].y};
+                p[c].hi = w2 * (f32x2){g[u][c].z, W4 ? g[u][c].w : 0.f};
+                if (!full && !((valid >> k) & 1u)) p[c].lo = p[c].hi = (f32x2){0.f, 0.f};   // (keeps 0 * inf of a repeated entry out)
             }
-            float4 v[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                v[c] = key[u] != kSegNone ? make_float4(w[u] * g[u][c].x, w[u] * g[u][c].y, w[u] * g[u][c].z, W4 ? w[u] * g[u][c].w : 0.f)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);   // (keeps 0 * inf of a clamped lane out)
-            // inclusive segmented scan over the 64 lanes (keys are sorted: equal keys are contiguous), on DPP moves:
-            // Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the last lane of a row handed to the
-            // next row (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) - if that lane's key is mine,
-            // everything between it and me has that key too, so its sum is exactly what my run is missing.
-            // (__shfl_up is ds_bpermute_b32 on gfx9: 36 trips through the CU's LDS crossbar per 64 entries kept this
-            // kernel at 186 us per 8-view batch whatever its HBM traffic was.)
-            seg_scan_step<0x111, 0xF, W4>(key[u], v);
-            seg_scan_step<0x112, 0xF, W4>(key[u], v);
-            seg_scan_step<0x114, 0xF, W4>(key[u], v);
-            seg_scan_step<0x118, 0xF, W4>(key[u], v);
-            seg_scan_step<0x142, 0xA, W4>(key[u], v);
-            seg_scan_step<0x143, 0xC, W4>(key[u], v);
-            const int key0 = __builtin_amdgcn_readlane(key[u], 0);
-            if (key[u] == key0 && key0 == carry_row) {                 // the run carried over from the previous 64 entries
-#pragma unroll
-                for (int c = 0; c < C; ++c) v[c] = f4_add(carry[c], v[c]);
-            } else if (lane == 0 && carry_row != kSegNone && carry_row != key0) {
-                // the carried run ended exactly at the 64-entry boundary: it is complete now
-                const bool is_head = carry_row == first_row && head_partial;
-                if (is_head) {
-                    rec_row[4 * wg] = carry_row;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = carry[c];
-                } else emit(carry_row, carry, true);
-            }
-            const int key_next = __builtin_amdgcn_update_dpp(kSegNone, key[u], 0x130, 0xF, 0xF, false);   // wave_shl:1 = lane + 1
-            const bool closed = lane != 63 && key_next != key[u] && key[u] != kSegNone;   // run ends inside these 64 entries
-            if (closed) {
-                if (key[u] == first_row && head_partial) {             // began in an earlier chunk: partial (head) record
-                    rec_row[4 * wg] = key[u];
-#pragma unroll
-                    for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = v[c];
-                } else emit(key[u], v, true);
-            }
-            carry_row = __builtin_amdgcn_readlane(key[u], 63);         // the run of the last lane stays open
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                carry[c] = make_float4(lane63(v[c].x), lane63(v[c].y), lane63(v[c].z), W4 ? lane63(v[c].w) : 0.f);
+            st.entry(s, PACKED ? st.key + (int)((counted >> k) & 1u) : rk[k], p, emit);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (lane == 0 && carry_row != kSegNone) {                          // the run still open at the end of the chunk
-        const bool complete = tail_complete;
-        const bool is_head = carry_row == first_row && head_partial;
-        if (complete && !is_head) emit(carry_row, carry, true);
-        else if (complete) {                                           // ends here, began earlier
-            rec_row[4 * wg] = carry_row;
-#pragma unroll
-            for (int c = 0; c < C; ++c) rec_val[(2 * wg) * C + c] = carry[c];
-        } else {                                                       // continues in the next chunk
-            rec_row[4 * wg + 1] = carry_row;
-            rec_row[4 * wg + 2] = is_head ? 0 : 1;                     // 1: the row STARTS in this chunk
-#pragma unroll
-            for (int c = 0; c < C; ++c) rec_val[(2 * wg + 1) * C + c] = carry[c];
-        }
-    }
+    bool tail_emitted;
+    seg_finish<C, W4>(st, lane, wg, kin, (starts & 1u) != 0u, first_row, head_partial, tail_complete, rec_row, rec_val, emit, tail_emitted);
 }
 
 template <int C>
@@ -349,8 +518,9 @@ __global__ __launch_bounds__(256) void gauss_seg_reduce_views_kernel(SegViews a)
         if (i < a.nv && vb >= a.block_start[i]) v = i;                 // block_start ascends
     const long wg = (vb - a.block_start[v]) * 4 + (threadIdx.x >> 6);
     if (wg >= a.chunks[v]) return;                                     // wave-uniform
+    __shared__ float4 lds[4][kSegLdsSlots * NF_SEG_LDS_MULT];                            // one slice per wave, never shared: no barriers
     seg_reduce_chunk<1, true, W4>(wg, threadIdx.x & 63, a.E[v], a.chunk_ord[v], a.packed[v], a.w_sorted[v], a.g_pix[v], 0, a.val[v],
-                                  a.n_rows[v], a.rec_row[v], a.rec_val[v]);
+                                  a.n_rows[v], a.rec_row[v], a.rec_val[v], lds[threadIdx.x >> 6]);
 }
 
 // ONE view, C right-hand sides (DeepFool's class gradients), over the view's compact index into val[C][n_rows].

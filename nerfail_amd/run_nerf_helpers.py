@@ -27,11 +27,16 @@ class _Img2Mse(torch.autograd.Function):
         return (None if ctx.dx is None else ctx.dx * g), None
 
 
+# the fused kernel is ONE workgroup (fixed-order tree, bitwise reproducible): right for a training batch (1024 rays x 3 = 3072
+# values: 3 sweeps per thread), a serial crawl for an image - anything larger takes torch's multi-workgroup reduction
+MSE_FUSED_MAX = 1 << 16
+
+
 def img2mse(x, y):
     """RH:9. On the MI355X (float32 HIP tensors of equal shape, target without gradient) one fused kernel; any other
     input takes the reference's expression."""
     if (isinstance(x, torch.Tensor) and isinstance(y, torch.Tensor) and x.is_cuda and y.is_cuda and x.dtype == torch.float32
-            and y.dtype == torch.float32 and x.shape == y.shape and not y.requires_grad and 0 < x.numel() < (1 << 22)):
+            and y.dtype == torch.float32 and x.shape == y.shape and not y.requires_grad and 0 < x.numel() <= MSE_FUSED_MAX):
         return _Img2Mse.apply(x, y)
     return torch.mean((x - y) ** 2)
 
@@ -203,6 +208,9 @@ class NeRF(nn.Module):
             self._f16_checked_once = True
             self._f16_verdict(float(m))
             return
+        # a measurement still on its way is WAITED for before its slot is reused: no verdict is ever overwritten unread
+        # (every pack is checked, one forward later at the latest - the training loop packs once per step)
+        self._f16_poll(wait=True)
         host = getattr(self, '_f16_host', None)
         if host is None:
             host = self._f16_host = torch.empty((1,), dtype=torch.float32).pin_memory()

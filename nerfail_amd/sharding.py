@@ -28,7 +28,8 @@ def world_and_rank(group=None):
     return 1, 0
 
 
-_STAGE = {}
+_STAGE = {}                 # (numel, dtype) -> pinned host buffer, insertion order = LRU order
+STAGE_SLOTS = 4             # gradient sizes in use at once: one per perturbation table shape
 
 
 def force_collectives():
@@ -50,9 +51,12 @@ def all_reduce_sum_(t, group=None):
         return t
     if t.is_cuda and str(dist.get_backend(group)) == 'gloo':
         key = (t.numel(), t.dtype)
-        h = _STAGE.get(key)
+        h = _STAGE.pop(key, None)
         if h is None:
-            h = _STAGE[key] = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+            h = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+            while len(_STAGE) >= STAGE_SLOTS:                 # bounded: the least recently used size goes
+                _STAGE.pop(next(iter(_STAGE)))
+        _STAGE[key] = h                                       # most recently used last
         h.copy_(t.reshape(-1), non_blocking=False)
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h.reshape(t.shape))

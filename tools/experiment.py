@@ -19,6 +19,8 @@ from nerfail_amd import build as B  # noqa: E402
 
 # name -> (source file, [(old, new), ...], extra compiler flags)
 EXPERIMENTS = {
+    # round 4, K11: the per-wave LDS slice doubled = half the waves per CU (how much does the segmented reduce depend on occupancy?)
+    'seg_lds2': ('gauss_csr.hip', [], ['-DNF_SEG_LDS_MULT=2']),
     'lds_base': ('mlp_lds.hip', [], []),
     'lds_gpm2': ('mlp_lds.hip', [], ['-DNF_LDS_GPM=2']),
     'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, hh, emb, demb);\n',
