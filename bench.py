@@ -14,7 +14,7 @@ group runs in a fresh child (`bench.py --child <group> --out <file>`, started wi
 touch the GPU) and appends its results to <file> one JSON object at a time, so whatever a child measured before it died is
 kept; a child that dies contributes `"<group>_error": "rc -6 ..."`. The parent prints ONE JSON line at the end whose
 contract keys (metric / value / ms_per_step / roofline / cpu_baseline ...) come from the `render` child, which runs first,
-with the `cpu` child (the three CPU baselines, no GPU) beside it on the host cores the render does not need.
+and the `cpu` child (the three CPU baselines, no GPU) right behind it.
 Groups: render | cpu | train (f32 + f16x3 step) | attack (gauss path, host-dataloader legs, end to end, DeepFool, cfg3) |
 extras (knn, f16x3 render). `--child <group>` without --out prints that group's objects to stdout: the form to put behind
 `rocprofv3 ... --` (a profiler-preloaded process must not start children).
@@ -1079,12 +1079,11 @@ def _guarded(emit, name, fn):
 
 
 def child_cpu(args, emit):
-    """The three CPU baselines (no GPU is touched). Runs beside the render child on N_CPU cores (the parent leaves two of the
-    box's cores to the render child's launch thread and to itself)."""
+    """The three CPU baselines (no GPU is touched), on all N_CPU cores of the cgroup quota, nothing else running."""
     _heavy_imports(gpu=False)
-    _guarded(emit, 'cpu_baseline', lambda: cpu_baseline(float(os.environ.get('NERFAIL_BENCH_CPU_SECONDS', '14'))))
-    _guarded(emit, 'cpu_baseline_fwd_bwd', lambda: cpu_baseline_fwd_bwd(8.0))
-    _guarded(emit, 'cpu_baseline_attack', lambda: cpu_baseline_attack(8.0))
+    _guarded(emit, 'cpu_baseline', lambda: cpu_baseline(float(os.environ.get('NERFAIL_BENCH_CPU_SECONDS', '12'))))
+    _guarded(emit, 'cpu_baseline_fwd_bwd', lambda: cpu_baseline_fwd_bwd(6.0))
+    _guarded(emit, 'cpu_baseline_attack', lambda: cpu_baseline_attack(6.0))
 
 
 def child_train(args, emit):
@@ -1192,7 +1191,6 @@ def parent_main(args, argv):
     t_start = time.time()
     sections = args.section_set
     line, status = {}, {}
-    total_cpus = N_CPU
 
     def finish(group, child):
         res, st = child.wait()
@@ -1205,21 +1203,17 @@ def parent_main(args, argv):
         if 'error' in st:
             line[group + '_error'] = st['error']
 
-    render = _Child('render', argv, timeout=120 + 4.0 * (args.steps + args.warmup)) if 'render' in sections else None
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline and 'cpu' in sections:
-        # beside the render child: that one needs a launch thread and nothing else (9 launches per 1.4 s view, queued ahead)
-        beside = render is not None
-        cpu = _Child('cpu', argv, timeout=200, env={'NERFAIL_BENCH_CPUS': str(max(1, total_cpus - 2) if beside else total_cpus)})
-    if render is not None:
-        finish('render', render)
+    if 'render' in sections:
+        finish('render', _Child('render', argv, timeout=120 + 4.0 * (args.steps + args.warmup)))
     if world > 1:                                    # the extra single-GPU sections belong to the N = 1 run
         if rank == 0:
             line['sections'] = status
             _print_line(line, world, args, t_start)
         sys.exit(0 if status.get('render', {}).get('rc', 1) == 0 else 1)
-    if cpu is not None:
-        finish('cpu', cpu)
+    if not args.no_cpu_baseline and 'cpu' in sections:
+        # right behind the render child, alone on the box's cores (run beside it - tried first in round 4 - the numpy port
+        # measured 687 rays/s on the 14 cores left over instead of 900 on all 16: the render child's launch thread spins)
+        finish('cpu', _Child('cpu', argv, timeout=200))
     if not args.no_attack:
         for group, need in (('train', {'train'}), ('attack', {'attack'}), ('extras', {'knn', 'f16x3'}), ('selftest', {'selftest'})):
             if sections & need:

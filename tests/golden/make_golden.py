@@ -323,6 +323,9 @@ def g7():
                 else:
                     out['%s_%s_gradnorm_%s' % (tag, nm, k)] = np.linalg.norm(gr.astype(np.float64))
                     out['%s_%s_gradhead_%s' % (tag, nm, k)] = gr.reshape(-1)[:256]
+                    # round 4: the whole tensor too (4.4 MB): a 256-element slice is one output neuron's row - a single ReLU
+                    # flip moves it by more than the whole tensor's L2 spread, so the per-parameter bound needs the tensor
+                    out['%s_%s_grad_%s' % (tag, nm, k)] = gr
     save('g7_train_grads', **out)
 
 

@@ -176,3 +176,103 @@ def test_f16x3_rejects_weights_outside_its_range():
         _mlp_points(net, pts, vd)                                           # this pack measures ...
         torch.cuda.synchronize()
         _mlp_points(net, pts, vd)                                           # ... and the next call reports
+
+
+TRAINED_WORST = {}
+
+
+def _sphere_target(rays):
+    """Analytic scene for a 'trained-like' net: a unit sphere shaded by its normal on a white background (white_bkgd)."""
+    o, d = rays[:, 0:3].astype(np.float64), rays[:, 3:6].astype(np.float64)
+    dn = d / np.linalg.norm(d, axis=1, keepdims=True)
+    b = (o * dn).sum(1)
+    disc = b * b - ((o * o).sum(1) - 1.0)
+    t = -b - np.sqrt(np.maximum(disc, 0.0))
+    hit = (disc > 0) & (t > 0)
+    nrm = o + dn * t[:, None]
+    rgb = np.where(hit[:, None], 0.5 + 0.5 * nrm, 1.0)
+    return rgb.astype(np.float32), hit
+
+
+def test_f16x3_on_trained_like_weights():
+    """everything above judges f16x3 on seeded random-init weights. Here both networks are TRAINED first -
+    2 000 Adam steps of the product's own exact-f32 training step (RN:776-801: 1024 random rays of 40 poses around an analytic
+    sphere, lr 5e-4 with the reference's decay) - and then asked the two questions that decide whether the mode could ever
+    be a default: (i) how far are the weights from the hard |w| < 64 limit of the fp16 image, (ii) does render_rays on the
+    trained weights still agree with the exact-f32 kernel and with the float64-accumulating oracle at the 1e-4 bound."""
+    from nerfail_amd import run_nerf as RN
+    from nerfail_amd.optim import Adam
+    from nerfail_amd.run_nerf import ray_gen
+    from hiputil import dev
+    sc, coarse = hip_nerf(8, 256, 71, requires_grad=True)
+    sf, fine = hip_nerf(8, 256, 72, requires_grad=True)
+    params = list(coarse.parameters()) + list(fine.parameters())
+    opt = Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    Hs = Ws = 100
+    focal, K = synth.lego_intrinsics(Hs, Ws)
+    rays_all = torch.cat([ray_gen(Hs, Ws, K, synth.pose_spherical(float(th), -30., 4.)[:3, :4], 2., 6.) for th in np.linspace(-180, 180, 41)[:-1]])
+    tgt_np, hit = _sphere_target(N(rays_all))
+    assert 0.05 < hit.mean() < 0.6
+    tgt_all = T(tgt_np)
+    gen = torch.Generator(device=dev()).manual_seed(0)
+    steps, first, last = 2000, None, None
+    for it in range(steps):
+        sel = torch.randint(0, rays_all.shape[0], (1024,), device=dev(), generator=gen)
+        r = RN.render_rays(rays_all[sel].contiguous(), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.,
+                           t_rand=torch.rand((1024, 64), device=dev(), generator=gen), u=torch.rand((1024, 128), device=dev(), generator=gen))
+        loss = RN.img2mse(r['rgb_map'], tgt_all[sel]) + RN.img2mse(r['rgb0'], tgt_all[sel])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for g in opt.param_groups:                                   # RN:796-800 (lrate_decay = 500 -> 500 000 steps)
+            g['lr'] = 5e-4 * 0.1 ** ((it + 1) / 500000.)
+        if it == 0:
+            first = float(loss.detach())
+    last = float(loss.detach())
+    assert np.isfinite(last) and last < 0.5 * first, (first, last)           # it really learned the scene
+    wmax0 = max(float(np.abs(v).max()) for k, v in {**sc, **sf}.items() if k.endswith('weight'))
+    wmax = max(float(p.detach().abs().max()) for n in (coarse, fine) for k, p in n.named_parameters() if k.endswith('weight'))
+    margin = coarse.F16X3_MAX_WEIGHT / wmax
+    print('trained-like weights: loss %.4f -> %.4f in %d steps; max |w| %.3f at init, %.3f trained: %.0fx below the f16x3 limit of %g'
+          % (first, last, steps, wmax0, wmax, margin, coarse.F16X3_MAX_WEIGHT))
+    assert margin > 8.0
+    # (ii) the same rays through both kernels and through the oracle, on the TRAINED weights
+    for n in (coarse, fine):
+        n.requires_grad_(False)
+    rays = rays_all[torch.arange(0, rays_all.shape[0], rays_all.shape[0] // 4096, device=dev())[:4096]].contiguous()
+    outs = {}
+    for prec in ('f32', 'f16x3'):
+        coarse.precision = fine.precision = prec
+        with torch.no_grad():
+            outs[prec] = RN.render_rays(rays, coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=0.)
+    worst = {}
+    for k in ('rgb_map', 'acc_map', 'rgb0'):
+        worst[k] = rel_err(N(outs['f16x3'][k]), N(outs['f32'][k]))
+        d = np.abs(N(outs['f16x3'][k]) - N(outs['f32'][k])).reshape(4096, -1).max(1)
+        worst[k + '_rays_over_1e-4'] = int((d > 1e-4).sum())
+    sd_c = {k: N(v) for k, v in coarse.state_dict().items()}
+    sd_f = {k: N(v) for k, v in fine.state_dict().items()}
+    nref = 256
+    ref = O.render_rays(N(rays[:nref]), sd_c, 64, 128, sd_f, white_bkgd=True)
+    for prec in ('f32', 'f16x3'):
+        for k in ('rgb_map', 'acc_map', 'rgb0'):
+            worst['%s_vs_oracle_%s' % (prec, k)] = rel_err(N(outs[prec][k][:nref]), ref[k])
+    for prec in ('f32', 'f16x3'):
+        worst['%s_vs_oracle_acc_map_abs' % prec] = float(np.abs(N(outs[prec]['acc_map'][:nref]) - ref['acc_map']).max())
+    worst['acc_map_abs'] = float(np.abs(N(outs['f16x3']['acc_map']) - N(outs['f32']['acc_map'])).max())
+    print('on trained weights: %s' % {k: ('%.1e' % v if isinstance(v, float) else v) for k, v in worst.items()})
+    TRAINED_WORST.update(worst)
+    # colours: the 1e-4 relative bound of every other parity test, split kernel vs exact kernel and both vs the oracle
+    for k in ('rgb_map', 'rgb0', 'f32_vs_oracle_rgb_map', 'f32_vs_oracle_rgb0', 'f16x3_vs_oracle_rgb_map', 'f16x3_vs_oracle_rgb0'):
+        assert worst[k] < 1e-4, (k, worst[k])
+    assert worst['rgb_map_rays_over_1e-4'] == 0 and worst['acc_map_rays_over_1e-4'] == 0
+    # accumulated opacity (in [0, 1]; white_bkgd adds 1 - acc to the colour held to 1e-4 above): a trained scene has nearly
+    # EMPTY rays (acc ~ 1e-2 and less), where conftest.rel_err (floor 1e-3 of the maximum) turns an absolute 6e-5 into "3e-3
+    # relative" - the exact-f32 kernel itself shows 1.6e-4 by that measure against the oracle. Absolute bounds instead.
+    # MEASURED (round 4): exact kernel vs oracle 5.6e-6, split kernel vs oracle 5.8e-6 (256 rays), split vs exact kernel over
+    # 4096 rays 6.4e-5 - inside 1e-4, but ~50x what the same comparison gives on random-init weights (3.6e-7): a trained
+    # density is sharp (sigma * delta ~ 10), and the split products' ~1e-6 relative error of raw sigma is an absolute error of
+    # alpha. After 2 000 steps the margin is 1.5x; a fully trained scene is sharper still. This is the evidence on which
+    # f16x3 STAYS OPT-IN (DESIGN.md K3+K4 split-precision variant).
+    assert worst['f32_vs_oracle_acc_map_abs'] < 2e-5 and worst['f16x3_vs_oracle_acc_map_abs'] < 2e-5, worst
+    assert worst['acc_map_abs'] < 1e-4, worst

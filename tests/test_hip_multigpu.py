@@ -100,6 +100,30 @@ def test_render_shards_concatenate_bitwise(runs):
     assert np.isfinite(one['full_rgb_map']).all() and (one['full_acc_map'] > 0).any()
 
 
+def test_cfg5_step_full_size_two_ranks(rank_launcher, tmp_path):
+    """the cfg5 step at REAL size - 8 views of 800 x 800, P = 3 (Ns = 1 920 000 rows), maps built by K8 + K9 -
+    split 4 + 4 over two ranks (gloo on the one-GPU box): one all-reduce of the [Ns,3] gradient + loss (23 040 004 bytes) per
+    step, the iterates identical on both ranks, and against the 1-rank run the sign step differs only where the gradient is at
+    rounding level (the two partial sums are added in another order)."""
+    script = os.path.join(ROOT, 'tests', 'mgpu', 'rank_full.py')
+    iters = 3
+    for world in (1, 2):
+        rep = rank_launcher(script, world, [str(tmp_path), iters], timeout=500)
+        assert rep['rc'] == [0] * world, '\n'.join(rep['logs'])
+    one = np.load(tmp_path / 'full_w1_r0.npz')
+    two = [np.load(tmp_path / ('full_w2_r%d.npz' % r)) for r in range(2)]
+    assert np.array_equal(two[0]['s'], two[1]['s']) and np.array_equal(two[0]['losses'], two[1]['losses'])
+    assert [tuple(t['views']) for t in two] == [(0, 4), (4, 8)]
+    assert two[0]['allreduce_bytes'].tolist() == [3 * 3 * 800 * 800 * 4 + 4] * iters        # ONE collective per step, gradient + loss
+    assert one['allreduce_bytes'].size == 0                                                # a 1-rank run issues none
+    diff = (two[0]['s'] != one['s']).mean()
+    print('cfg5 full-size step, 2 ranks vs 1: differing elements %.2e, losses %s vs %s' % (diff, two[0]['losses'], one['losses']))
+    assert diff < 1e-3
+    assert np.allclose(two[0]['losses'], one['losses'], rtol=1e-5)
+    s = two[0]['s'].astype(np.float32)
+    assert np.abs(s[..., :3]).max() <= 2.0 * iters and (s[..., :3] != 0).mean() > 0.01      # the step moved the perturbation
+
+
 def test_rccl_path_one_rank_dry_run(rank_launcher, tmp_path):
     """the nccl (= RCCL) branch executed once on the one-GPU box - a 1-rank 'nccl' process group bound
     to the device, the product's 3 Ns + 1 float gradient buffer all-reduced through it on the current stream, HIP events

@@ -64,17 +64,29 @@ def test_training_step_gradients(golden, tag, D, W):
     loss.backward()
     assert abs(float(loss.detach()) - float(g[tag + '_loss'])) < 1e-5 * abs(float(g[tag + '_loss']))
     assert rel_err(N(r['rgb_map']), g[tag + '_rgb_map']) < 1e-4
+    # Per-parameter bound from a MEASURED quantity (as :test_mlp_backward_on_identical_inputs does for the
+    # isolated MLP): fixture g7 holds, for this very step, the reference's own gradients in fp32 AND in fp64 (same rays, draws
+    # and weights) - their L2 distance per parameter is what rounding alone does to the reference (ReLU kinks and
+    # importance-sampling bins that flip included: 1e-7 .. 5e-3 depending on the layer). The HIP step must agree with the
+    # reference's fp32 gradient within 2 x that + eps. eps = 2e-6 (sin/cos, MFMA summation order), except
+    #   * alpha_linear.*: eps = 3e-4. Its gradient is the sum of d sigma over all samples, and d sigma comes out of the
+    #     composite backward's suffix sums sum_{k>i} g_k w_k - cancellation-prone, scanned in fp32 by wave shuffles here and by
+    #     torch's double-accumulating cumsum / cumprod in the reference: measured 1.1e-4 (coarse, D8 W256)
+    #     where the reference's own spread happens to be 6e-6.
     ref = O.train_step_grads(rays, sc, sf, target, t_rand=g[tag + '_t_rand'], u=g[tag + '_u'], D=D, W=W)
+    worst, lines = 0.0, []
     for nm, net in (('coarse', coarse), ('fine', fine)):
         for k, p in net.named_parameters():
             got = N(p.grad)
-            assert l2_err(got, ref['grads_' + nm][k]) < 5e-3, (nm, k)              # vs the float64 oracle
-            if tag == 'small':                                                       # vs the reference's autograd
-                assert l2_err(got, g['small_%s_grad_%s' % (nm, k)]) < 5e-3, (nm, k)
-            else:
-                refn = float(g['full_%s_gradnorm_%s' % (nm, k)])
-                assert abs(np.linalg.norm(got.astype(np.float64)) - refn) < 5e-3 * refn, (nm, k)
-                assert l2_err(got.reshape(-1)[:256], g['full_%s_gradhead_%s' % (nm, k)]) < 5e-3, (nm, k)
+            e = l2_err(got, g['%s_%s_grad_%s' % (tag, nm, k)])                      # vs the reference's autograd (fp32), whole tensor
+            spread = float(g['%s_%s_referr_%s' % (tag, nm, k)])
+            bound = 2 * spread + (3e-4 if k.startswith('alpha_linear') else 2e-6)
+            worst = max(worst, e / bound)
+            lines.append('%-6s %-26s err %.2e  reference fp32-vs-fp64 %.2e  bound %.2e' % (nm, k, e, spread, bound))
+            assert l2_err(got, ref['grads_' + nm][k]) < 5e-3, (nm, k)              # and the float64-backward oracle, loosely
+    print('\n'.join(lines))
+    print('HIP training step (%s) vs the reference step: worst error / bound = %.2f' % (tag, worst))
+    assert worst <= 1.0, '\n'.join(lines)
 
 
 def test_training_loop_adam_reduces_loss():
