@@ -21,6 +21,7 @@ from nerfail_amd import build as B  # noqa: E402
 EXPERIMENTS = {
     # round 4, K11: the per-wave LDS slice doubled = half the waves per CU (how much does the segmented reduce depend on occupancy?)
     'seg_lds2': ('gauss_csr.hip', [], ['-DNF_SEG_LDS_MULT=2']),
+    # (the round-2/3 ablations of the old entry-strided reduce - seg_noscan / _nogather / _noemit / _u16 / _u4 - went with that kernel)
     'lds_base': ('mlp_lds.hip', [], []),
     'lds_gpm2': ('mlp_lds.hip', [], ['-DNF_LDS_GPM=2']),
     'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, hh, emb, demb);\n',
@@ -104,11 +105,6 @@ EXPERIMENTS = {
     'dw_nofetch': ('mlp_dw.hip', [('        R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n', '        if (off == -12345) R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n')], []),
     'dw_norowsum': ('mlp_dw.hip', [('                rowsum[m] = rowsum[m] + (R[P][m][0] + R[P][m][1]);\n', '')], []),
     # K11 segmented reduce pricing: no wave scan (wrong sums) / no gathers (index stream only)
-    'seg_noscan': ('gauss_csr.hip', [('            seg_scan_step<0x111, 0xF, W4>(key[u], v);\n            seg_scan_step<0x112, 0xF, W4>(key[u], v);\n            seg_scan_step<0x114, 0xF, W4>(key[u], v);\n            seg_scan_step<0x118, 0xF, W4>(key[u], v);\n            seg_scan_step<0x142, 0xA, W4>(key[u], v);\n            seg_scan_step<0x143, 0xC, W4>(key[u], v);\n', '')], []),
-    'seg_nogather': ('gauss_csr.hip', [('            for (int c = 0; c < C; ++c) g[u][c] = g_pix[(long)(id[u] >> (PACKED ? 1 : 3)) * C + c];', '            for (int c = 0; c < C; ++c) g[u][c] = make_float4((float)id[u], 1.f, 2.f, 3.f);')], []),
-    'seg_noemit': ('gauss_csr.hip', [('        if (!owner) return;\n#pragma unroll\n        for (int c = 0; c < C; ++c) {\n            float4 o = v[c];', '        if (!owner || row != -12345) return;\n#pragma unroll\n        for (int c = 0; c < C; ++c) {\n            float4 o = v[c];')], []),
-    'seg_u16': ('gauss_csr.hip', [('constexpr int kSegU = 8; ', 'constexpr int kSegU = 16;')], []),
-    'seg_u4': ('gauss_csr.hip', [('constexpr int kSegU = 8; ', 'constexpr int kSegU = 4; ')], []),
     # K8 grid resolution: cells per axis = scale * cbrt(n) (1.5: 7.6 ms, 2.0: 7.7 ms per rendered-view map against 8.3 ms; shell
     # points 2.0 / 1.0 ms against 1.3 ms - no clear winner, the search is latency bound)
     # K8 far search: wave-level counters -> stats[2..9] (tools/debug/knn_profile.py)
