@@ -128,7 +128,7 @@ def kernel_source_hash():
 KERNEL_SOURCES = {'nerf_mlp_fwd_lds_kernel': ('mlp_lds.hip', 'mlp_layout.h', 'common.h'),
                   'gauss_': ('gauss.hip', 'gauss_csr.hip', 'common.h'), 'igsm_': ('gauss.hip', 'common.h'),
                   'seg_': ('gauss_csr.hip', 'common.h')}
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(kernel_substr, which='avg'):

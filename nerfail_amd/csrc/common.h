@@ -74,6 +74,35 @@ __device__ __forceinline__ double wave_scan_add_f64(double v, int lane) {
     return v;
 }
 
+// ---- the same on DPP moves (row_shr 1 2 4 8 inside each row of 16 lanes, then row_bcast:15 / :31 hand the last lane of a row
+// to the rows behind): no trip through the LDS crossbar (__shfl_* is ds_bpermute / ds_swizzle on gfx9), one VALU instruction
+// per step. The inclusive result of lane 63 is the wave total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move_f(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_scan_add_dpp(float v) {          // inclusive sum scan
+    v += dpp_move_f<0x111, 0xF>(0.f, v);
+    v += dpp_move_f<0x112, 0xF>(0.f, v);
+    v += dpp_move_f<0x114, 0xF>(0.f, v);
+    v += dpp_move_f<0x118, 0xF>(0.f, v);
+    v += dpp_move_f<0x142, 0xA>(0.f, v);
+    v += dpp_move_f<0x143, 0xC>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul_dpp(float v) {          // inclusive product scan
+    v *= dpp_move_f<0x111, 0xF>(1.f, v);
+    v *= dpp_move_f<0x112, 0xF>(1.f, v);
+    v *= dpp_move_f<0x114, 0xF>(1.f, v);
+    v *= dpp_move_f<0x118, 0xF>(1.f, v);
+    v *= dpp_move_f<0x142, 0xA>(1.f, v);
+    v *= dpp_move_f<0x143, 0xC>(1.f, v);
+    return v;
+}
+__device__ __forceinline__ float wave_total_dpp(float v) {             // sum of the 64 lanes, wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan_add_dpp(v)), 63));
+}
+
 // Correctly rounded float32 sqrt. NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS the HIP headers
 // map that to __ocml_native_sqrt_f32 (approximate). sqrtf is IEEE-rounded under hipcc's default
 // -fhip-fp32-correctly-rounded-divide-sqrt, like the `/` behind __fdiv_rn.

@@ -4,13 +4,24 @@
 // One wavefront per ray. Lane l owns IPL consecutive samples (IPL = ceil(N/64): 1 for the 64 coarse
 // samples, 3 for the 192 fine ones), so every global access is a contiguous run per lane and a
 // contiguous span per wave. The exclusive transmittance cumprod is a lane-local product followed by a
-// 64-lane shuffle scan; the ray sums are shuffle reductions. No LDS.
+// 64-lane scan; the ray sums are wave totals. No LDS - round 4: not the LDS crossbar either (the scans and totals run on
+// DPP moves instead of __shfl_*: ~36 ds_bpermute trips per ray gone), and the rgb sigmoid 1 / (1 + exp(-x)) uses v_exp_f32 and
+// v_rcp_f32 (1-2 ulp each: 1e-7 of a colour that is compared at 1e-4) instead of the correctly rounded expf and division,
+// which were two thirds of the kernel's ~90 vector instructions per sample. alpha = 1 - exp(-sigma dist) keeps the accurate
+// expf: it cancels for faint samples, where one ulp of exp is 1e-4 of the weight.
 //
 // HBM-bound: algorithmic bytes per ray = 24*N + 36 (+12*N+12 when pts_max is requested: it reads one
 // point per ray, 12 B, the figure quoted in DESIGN.md uses the raw2outputs form).
 #include "common.h"
 
 namespace nerfail {
+
+// 1 / (1 + exp(-x)) on the hardware transcendentals: v_exp_f32 (2^x, 1 ulp) of -x * log2(e), v_rcp_f32 (1 ulp). exp(-x) -> inf
+// for x << 0 gives rcp(inf) = 0, like the reference's sigmoid; NaN propagates. (__frcp_rn / __expf compile to the correctly
+// rounded division and the full expf in this HIP build.)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
 
 template <int IPL>
 __global__ __launch_bounds__(256) void composite_kernel(
@@ -50,16 +61,15 @@ __global__ __launch_bounds__(256) void composite_kernel(
             if (noise != nullptr) sigma = __fadd_rn(sigma, noise[base + i]);
             sigma = fmaxf(sigma, 0.0f);
             alpha[k] = __fsub_rn(1.0f, expf(-__fmul_rn(sigma, dist)));
-            rgbr[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.x)));
-            rgbg[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.y)));
-            rgbb[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.z)));
+            rgbr[k] = fast_sigmoid(rw.x);
+            rgbg[k] = fast_sigmoid(rw.y);
+            rgbb[k] = fast_sigmoid(rw.z);
             tprod = __fmul_rn(tprod, __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f));
         }
     }
     // exclusive scan of lane products -> transmittance in front of this lane's first sample
-    const float incl = wave_scan_mul(tprod, lane);
-    float T = __shfl_up(incl, 1, 64);
-    if (lane == 0) T = 1.0f;
+    const float incl = wave_scan_mul_dpp(tprod);
+    float T = dpp_move_f<0x138, 0xF>(1.0f, incl);            // wave_shr:1 - lane l receives lane l - 1, lane 0 the identity
 
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
     float best_w = -1.0f;
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
             T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f));
         }
     }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+    sr = wave_total_dpp(sr); sg = wave_total_dpp(sg); sb = wave_total_dpp(sb); sd = wave_total_dpp(sd); sa = wave_total_dpp(sa);
 
     if (pts_max != nullptr) {   // torch.argmax returns the FIRST maximal index (NC:418)
 #pragma unroll
