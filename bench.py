@@ -663,9 +663,9 @@ def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
     """K10 / K11 / K12 of the step path (rgb-gradient form) one by one through the C-ABI, HIP events on the launch stream.
     Bytes: `compulsory_bytes_per_call` = what THIS form has to move once (counted from the maps: background pixels read
     their 32 bytes of weights only; the index stream of K11 is part of it), `survey_bytes_per_call` = SURVEY.md section 8d's
-    nominal figure (fp32 x and ori, four gradient channels) for reference. roofline.achieved / frac are taken from the PMC
-    traffic of the kernels when the stored counters belong to these sources (traffic / time: a rate that cannot exceed
-    the HBM peak), else from the compulsory bytes; K12's tables (3 x 30.7 MB) would sit in the 256 MB Infinity Cache across
+    nominal figure (fp32 x and ori, four gradient channels) for reference. roofline.achieved / frac = compulsory bytes / time
+    (round 4; algorithmic bytes, as for every other roofline of this file); roofline.traffic = the kernels' PMC bytes when
+    the stored counters belong to these sources; K12's tables (3 x 30.7 MB) would sit in the 256 MB Infinity Cache across
     back-to-back calls, so its calls rotate over 4 table sets (368 MB) and use distinct s / s_init buffers."""
     from nerfail_amd import _lib
     from nerfail_amd.GaussNet import resolve_views, view_table
@@ -728,13 +728,14 @@ def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
         for k in kernels:                                     # PMC bytes per launch (every kernel launches once per call)
             t, src = pmc_traffic(k, 'max')                    # the 8-view batch is these kernels' largest launch
             traffic = None if (t is None or traffic is None) else traffic + t
-        moved = traffic if traffic is not None else comp
-        rate = moved / ms / 1e6
+        rate = comp / ms / 1e6                                # ALGORITHMIC (compulsory) bytes of this form per second
         out[name] = {'ms_per_call': ms, 'statistic': 'fastest of 3 blocks of %d calls' % n, 'kernels': list(kernels),
                      'compulsory_bytes_per_call': comp, 'survey_bytes_per_call': survey,
-                     'roofline': {'bound': 'hbm', 'achieved': rate, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': min(rate / HBM_PEAK_GBS, 1.0),
-                                  'bytes_used': 'pmc traffic' if traffic is not None else 'compulsory bytes of this form',
+                     'roofline': {'bound': 'hbm', 'achieved': rate, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': rate / HBM_PEAK_GBS,
+                                  'bytes_used': 'compulsory bytes of this form',
                                   'traffic': traffic, 'traffic_source': src,
+                                  'traffic_note': 'PMC FETCH_SIZE x2 + WRITE_SIZE per call; the x2 of MI355X_MICROARCH.md is calibrated for wide '
+                                                  'coalesced reads, not for the 16-byte gathers of these kernels: an upper estimate',
                                   'survey_nominal_GBps': survey / ms / 1e6}}
     out['inverted_index_bytes_per_view'] = int(sum(vi.nbytes() for vi in vis) / len(vis))
     out['foreground_pixel_fraction'] = fg
@@ -1265,8 +1266,8 @@ def _print_line(line, world, args, t_start):
                                        value_iters_per_sec=a['gauss_path_deterministic']['iters_per_sec'])
         gk = a.get('gauss_kernels')
         if isinstance(gk, dict):                     # per-kernel time and bytes
-            line['roofline_attack']['per_kernel'] = {k: {'ms': v['ms_per_call'], 'bytes': v['roofline'].get('traffic') or v['compulsory_bytes_per_call'],
-                                                         'bytes_kind': v['roofline']['bytes_used'], 'frac': v['roofline']['frac']}
+            line['roofline_attack']['per_kernel'] = {k: {'ms': v['ms_per_call'], 'bytes': v['compulsory_bytes_per_call'],
+                                                         'pmc_bytes': v['roofline'].get('traffic'), 'frac': v['roofline']['frac']}
                                                      for k, v in gk.items() if isinstance(v, dict) and 'ms_per_call' in v}
     line.setdefault('cpu_baseline', None)
     line['wall_seconds'] = round(time.time() - t_start, 1)

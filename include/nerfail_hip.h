@@ -326,7 +326,8 @@ int nerfail_gauss_view_pack(const int32_t* row_ptr, const int32_t* row_of, const
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* One view's inverted index in compact form (nerfail_gauss_view_pack). All pointers are device memory; the counts are
- * host values (read back once when the index is built). */
+ * host values (read back once when the index is built). `packed` and `w_sorted` are read 16 bytes per lane at multiples of 8
+ * entries: keep them 16-byte aligned (any allocator does; a slice starting at an odd entry still works, slower). */
 typedef struct nerfail_view_index {
     const int32_t* packed;     /* [n_entries] pixel * 2 + row-start flag, entries sorted by destination row             */
     const float* w_sorted;     /* [n_entries] the entry's Gaussian weight                                               */

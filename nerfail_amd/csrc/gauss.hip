@@ -151,21 +151,26 @@ __global__ __launch_bounds__(256) void gauss_fwd_views_kernel(const float4* __re
         if (any) {
             const float4 ia = i4[0], ib = i4[1];
             const float fi[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+            const int last = (int)Ns - 1;     // (the launcher checks Ns < 2^31)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {     // issue all 8 gathers before using any
-                long j = (long)fi[k];         // .type(torch.long): truncation (GN:62)
-                j = j < 0 ? 0 : (j >= Ns ? Ns - 1 : j);
+                // .type(torch.long): truncation (GN:62). Through int32 (round 4): v_cvt_i32_f32 truncates, saturates and turns
+                // NaN into 0 in ONE instruction - after the clamp the same row as the 64-bit conversion picks for every
+                // float, which cost ~10 vector instructions per index (80 of this kernel's 286 per wave)
+                int j = (int)fi[k];
+                j = j < 0 ? 0 : (j > last ? last : j);
                 rows[k] = spatial[j];         // unconditional: a per-gather "skip if w == 0" branch serialises the 8 loads
             }
         }
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 xlo = {0.f, 0.f}, xhi = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {     // x = sum_k s[idx_k] * w_k, sequential in k (GN:81-83)
-            x.x = __fadd_rn(x.x, __fmul_rn(rows[k].x, w[k]));
-            x.y = __fadd_rn(x.y, __fmul_rn(rows[k].y, w[k]));
-            x.z = __fadd_rn(x.z, __fmul_rn(rows[k].z, w[k]));
-            x.w = __fadd_rn(x.w, __fmul_rn(rows[k].w, w[k]));
+        for (int k = 0; k < 8; ++k) {     // x = sum_k s[idx_k] * w_k, sequential in k (GN:81-83); multiply, then add (no
+            const f32x2 w2 = {w[k], w[k]};    // contraction: -ffp-contract=off), two channels per v_pk_mul_f32 / v_pk_add_f32
+            xlo = xlo + (f32x2){rows[k].x, rows[k].y} * w2;
+            xhi = xhi + (f32x2){rows[k].z, rows[k].w} * w2;
         }
+        const float4 x = make_float4(xlo.x, xlo.y, xhi.x, xhi.y);
         float alpha;
         unsigned mask;
         float4 xr;
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(256) void igsm_step_rgb_kernel(const float4* __rest
 
 static int launch_fwd_views(const float4* spatial, long Ns, const FwdViews& tab, long P, bool ori_u8, float epsilon, float4* x,
                             float4* x_rgba, float* aux_alpha, unsigned char* aux_mask, float* eps_minmax, hipStream_t s) {
+    if (Ns >= (1L << 31)) { set_error("nerfail_gauss_fwd: the perturbation table must have fewer than 2^31 rows"); return NERFAIL_EINVAL; }
     const int bpv = (int)((P + 255) / 256);
     const unsigned blocks = (unsigned)((((long)tab.nv * bpv + 7) / 8) * 8);
     if (ori_u8) gauss_fwd_views_kernel<true><<<dim3(blocks), dim3(256), 0, s>>>(spatial, Ns, tab, P, bpv, epsilon, x, x_rgba, aux_alpha, aux_mask, eps_minmax);
