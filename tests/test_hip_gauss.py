@@ -245,6 +245,59 @@ def test_backward_with_very_long_rows():
         assert rel_err(N(auto).reshape(-1, 4), N(single)) < 1e-5, c
 
 
+@pytest.mark.parametrize('n_total', [512 * 5 + 1, 512 * 5 + 7, 512 * 5 + 8, 512 * 5 + 9, 512 * 5 + 63, 512 * 5 + 64, 512 * 5 + 65,
+                                     512 * 6 - 1, 512 * 6, 511, 8, 1])
+def test_segmented_reduce_on_adversarial_row_layouts(n_total):
+    """Round 4 rebuilt the inverted-index reduce (a lane owns 8 consecutive entries, one cross-lane scan per 512-entry chunk,
+    an LDS-transposed route for full chunks and a direct one for the partial last chunk). The index of a view is the list of
+    its non-zero-weight contributions sorted by row, so the row layout can be dictated exactly: a row of exactly 3 chunks, rows
+    that end ON a chunk boundary, rows of exactly one lane (8 entries) aligned and misaligned, a 2 000-entry row across
+    several chunks, 600 single-entry rows in sequence, and every kind of partial tail (n_total). Deterministic gradient vs the
+    oracle's scatter-add, bitwise repeatable, equal to the float-atomic form to rounding."""
+    from nerfail_amd.GaussNet import gauss_gather
+    from nerfail_amd import GaussNet as G
+    rs = np.random.RandomState(n_total)
+    H, W, P = 24, 20, 3                                         # 480 pixels x 8 slots = 3 840 contribution slots
+    Ns = P * H * W
+    pattern = [1536, 1, 511, 8, 8, 8, 3, 8, 8, 5, 2000] + [1] * 600 + [9, 7, 512, 512, 17]
+    lens, left = [], n_total
+    for L_ in pattern:
+        if left <= 0:
+            break
+        lens.append(min(L_, left))
+        left -= lens[-1]
+    assert sum(lens) == n_total <= H * W * 8
+    rows = np.cumsum(rs.randint(1, 4, size=len(lens)))          # ascending row ids with empty rows in between
+    assert rows[-1] < Ns
+    slot_row = np.repeat(rows, lens)                            # sorted entry order == slot order (ascending contribution id)
+    idx = np.zeros(H * W * 8, np.float32)
+    w = np.zeros(H * W * 8, np.float32)
+    idx[:n_total] = slot_row
+    w[:n_total] = rs.uniform(0.1, 1.0, n_total)
+    idx[n_total:] = rs.randint(0, Ns, H * W * 8 - n_total)      # weight 0: dropped from the index
+    wi_np = np.stack([w.reshape(1, H, W, 8), idx.reshape(1, H, W, 8)], 1).astype(np.float32)
+    s = rs.uniform(-30, 30, (P, H, W, 4)).astype(np.float32)
+    s[..., 3] = 255.0
+    ori = synth.disc_alpha_image(1, H, W, seed=9)
+    ori[..., 3] = 255.0                                         # every pixel opaque: every gradient passes
+    Gr = rs.normal(size=(1, H, W, 4)).astype(np.float32)
+    G._VIEW_CACHE.clear(); G._BATCH_KEYS.clear()
+    grads = {}
+    for det in (True, True, False):
+        st = T(s).requires_grad_(True)
+        x, xr = gauss_gather(st, T(wi_np), T(ori), None, None, det)
+        (xr * T(Gr)).sum().backward()
+        grads.setdefault(det, []).append(N(st.grad))
+    assert np.array_equal(grads[True][0], grads[True][1])       # fixed order: the same bits
+    ref = OG.gauss_backward(s, wi_np, ori, np.zeros_like(Gr), Gr, None)
+    scale = np.abs(ref).max()
+    assert np.abs(grads[True][0] - ref).max() <= 2e-5 * scale
+    assert np.abs(grads[False][0] - ref).max() <= 2e-5 * scale
+    vi = G.view_indices(T(wi_np), Ns)[0]
+    assert vi.n_entries == n_total and vi.n_rows == len(lens)
+    G._VIEW_CACHE.clear(); G._BATCH_KEYS.clear()
+
+
 def test_cfg3_loop_matches_reference_iterates(golden):
     """BASELINE configs[2] at fixture size (g15): 20 iterations x 2 batches of 8 views, sequential update, through
     attack.nerfail_s_loop (HIP gauss forward, deterministic inverted-index backward, sign-step kernel) against the
