@@ -1025,7 +1025,7 @@ def child_render(args, emit):
                          'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
                          'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
             # the other roofline the north star asks for: achieved HBM rate of the compositing scan (K5 + K7)
-            'composite_scan': {'bound': 'hbm', 'kernel': 'composite_kernel<1|3>', 'achieved': comp_bytes / max(comp_ms, 1e-9) / 1e6,
+            'composite_scan': {'bound': 'hbm', 'kernel': 'composite2_kernel<2|6>', 'achieved': comp_bytes / max(comp_ms, 1e-9) / 1e6,
                                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': comp_bytes / max(comp_ms, 1e-9) / 1e6 / HBM_PEAK_GBS,
                                'launches': len(comp_events), 'ms_total': comp_ms,
                                'note': 'algorithmic 24N+36 B per ray (coarse N=64 and fine N=192 launches together)'},
