@@ -266,7 +266,8 @@ extern "C" int nerfail_composite(const float* raw, const float* z_vals, const fl
     NF_REQUIRE(rgb_map != nullptr && disp_map != nullptr && acc_map != nullptr, "rgb_map / disp_map / acc_map is NULL");
     NF_REQUIRE(pts == nullptr || pts_max != nullptr, "pts is only read for pts_max");
     hipStream_t s = as_stream(stream);
-    static const bool one_ray_form = getenv("NERFAIL_COMPOSITE_KERNEL") != nullptr && getenv("NERFAIL_COMPOSITE_KERNEL")[0] == '1';   // A/B runs
+    const char* sel = getenv("NERFAIL_COMPOSITE_KERNEL");            // "1": the one-ray-per-wave form (A/B runs, tests); read per call
+    const bool one_ray_form = sel != nullptr && sel[0] == '1';
     if (n_samples % 32 == 0 && !one_ray_form) {              // two rays per wave (64, 192 and every other multiple of 32)
         const dim3 block2(256), grid2((unsigned)((n_rays + 7) / 8));
 #define NF_COMPOSITE2(IPL)                                                                                                \
