@@ -6,18 +6,33 @@
 //     dL/dalpha = gw_i * T_i - (sum_{k>i} gw_k w_k) / (1 - alpha_i + 1e-10)         (cumprod backward)
 //     dL/dsigma = dL/dalpha * dist_i * exp(-sigma_i dist_i) * [sigma_i > 0]
 //     dL/draw_c = w_i * g_rgb_c * c (1 - c)
-// with the suffix sum as a reverse 64-lane shuffle scan. g_disp is folded into g_depth / g_acc through
+// with the suffix sum as a reverse 64-lane shuffle scan in double precision (as torch's CPU cumsum accumulates). g_disp is folded into g_depth / g_acc through
 // disp = 1/max(1e-10, depth/acc). HBM-bound: reads 20N+..., writes 16N bytes per ray.
 #include "common.h"
 
 namespace nerfail {
 
-// inclusive suffix sum across lanes: out[l] = sum_{m >= l} v[m]
-__device__ __forceinline__ float wave_suffix_sum(float v, int lane) {
+// inclusive suffix sum across lanes: out[l] = sum_{m >= l} v[m]. Double precision (round 5): torch's cumprod backward is
+// reversed_cumsum(grad * output) / input, and the CPU cumsum accumulates fp32 inputs in double (acc_type<float, false>),
+// so the reference's own fp32 path carries this sum wider than fp32; an fp32 shuffle scan was ~20x noisier than the
+// reference's fp32-vs-fp64 spread on alpha_linear's gradient. The kernel is 0.1 % of a training step.
+__device__ __forceinline__ double wave_suffix_sum_f64(double v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const float t = __shfl_down(v, o, 64);
+        const double t = __shfl_down(v, o, 64);
         if (lane + o < 64) v += t;
+    }
+    return v;
+}
+
+// inclusive product scan across lanes in double. torch's CPU cumprod (RN:295) keeps its running product in double as well
+// (acc_type<float, false>) and rounds it to fp32 per position: with the double scan T_i here IS that value, and the
+// cancellation in dL/dalpha = gw_i T_i - S_i / (1 - alpha_i + 1e-10) no longer amplifies a product-tree rounding of T.
+__device__ __forceinline__ double wave_scan_mul_f64(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
     }
     return v;
 }
@@ -40,7 +55,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     float z[IPL + 1], alpha[IPL], ex[IPL], dist[IPL], sig[IPL], cr[IPL], cg[IPL], cb[IPL], tt[IPL];
 #pragma unroll
     for (int k = 0; k <= IPL; ++k) z[k] = (i0 + k < N) ? z_vals[base + i0 + k] : 0.0f;
-    float tprod = 1.0f;
+    double tprod = 1.0;
 #pragma unroll
     for (int k = 0; k < IPL; ++k) {
         const int i = i0 + k;
@@ -59,12 +74,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             cg[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.y)));
             cb[k] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-rw.z)));
             tt[k] = __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f);
-            tprod = __fmul_rn(tprod, tt[k]);
+            tprod *= (double)tt[k];
         }
     }
-    const float incl = wave_scan_mul(tprod, lane);
-    float T0 = __shfl_up(incl, 1, 64);
-    if (lane == 0) T0 = 1.0f;
+    const double incl = wave_scan_mul_f64(tprod, lane);
+    double T0 = __shfl_up(incl, 1, 64);
+    if (lane == 0) T0 = 1.0;
 
     float gr = 0.f, gg = 0.f, gb = 0.f;
     if (g_rgb != nullptr) { gr = g_rgb[3 * ray]; gg = g_rgb[3 * ray + 1]; gb = g_rgb[3 * ray + 2]; }
@@ -73,13 +88,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     if (white_bkgd) ga -= (gr + gg + gb);                  // rgb_map += 1 - acc
     float T[IPL], w[IPL];
     {
-        float Tk = T0, sd = 0.f, sa = 0.f;
+        double Tk = T0;
+        float sd = 0.f, sa = 0.f;
 #pragma unroll
         for (int k = 0; k < IPL; ++k) {
-            T[k] = Tk;
-            w[k] = __fmul_rn(alpha[k], Tk);
+            T[k] = (float)Tk;
+            w[k] = __fmul_rn(alpha[k], T[k]);
             if (i0 + k < N) { sd += w[k] * z[k]; sa += w[k]; }
-            Tk = __fmul_rn(Tk, tt[k]);
+            Tk *= (double)tt[k];
         }
         if (g_disp != nullptr) {                           // disp = 1 / max(1e-10, depth / acc)
             sd = wave_sum(sd); sa = wave_sum(sa);
@@ -91,28 +107,29 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
             }
         }
     }
-    float gw[IPL], gww = 0.f;
+    float gw[IPL], gp[IPL];
+    double gww = 0.0;
 #pragma unroll
     for (int k = 0; k < IPL; ++k) {
-        gw[k] = 0.f;
+        gw[k] = 0.f; gp[k] = 0.f;
         if (i0 + k < N) {
             gw[k] = gr * cr[k] + gg * cg[k] + gb * cb[k] + ga + gd * z[k];
             if (g_weights != nullptr) gw[k] += g_weights[base + i0 + k];
-            gww += gw[k] * w[k];
+            gp[k] = __fmul_rn(__fmul_rn(gw[k], alpha[k]), T[k]);     // grad_T * T, an fp32 product as autograd forms it
+            gww += (double)gp[k];
         }
     }
-    // S for this lane's LAST sample = sum over later lanes; walk backwards inside the lane
-    const float suffix_incl = wave_suffix_sum(gww, lane);
-    float S = suffix_incl - gww;                           // contributions of lanes > this one
+    // S for this lane's LAST sample = sum over later lanes; walk backwards inside the lane (all of it in double)
+    double S = wave_suffix_sum_f64(gww, lane) - gww;       // contributions of lanes > this one
 #pragma unroll
     for (int k = IPL - 1; k >= 0; --k) {
         const int i = i0 + k;
         if (i < N) {
-            const float dalpha = gw[k] * T[k] - S / tt[k];
+            const float dalpha = __fsub_rn(__fmul_rn(gw[k], T[k]), __fdiv_rn((float)S, tt[k]));
             const float dsig = (sig[k] > 0.f) ? dalpha * dist[k] * ex[k] : 0.f;
             d_raw[base + i] = make_float4(w[k] * gr * cr[k] * (1.f - cr[k]), w[k] * gg * cg[k] * (1.f - cg[k]),
                                           w[k] * gb * cb[k] * (1.f - cb[k]), dsig);
-            S += gw[k] * w[k];
+            S += (double)gp[k];
         }
     }
 }

@@ -68,11 +68,9 @@ def test_training_step_gradients(golden, tag, D, W):
     # isolated MLP): fixture g7 holds, for this very step, the reference's own gradients in fp32 AND in fp64 (same rays, draws
     # and weights) - their L2 distance per parameter is what rounding alone does to the reference (ReLU kinks and
     # importance-sampling bins that flip included: 1e-7 .. 5e-3 depending on the layer). The HIP step must agree with the
-    # reference's fp32 gradient within 2 x that + eps. eps = 2e-6 (sin/cos, MFMA summation order), except
-    #   * alpha_linear.*: eps = 3e-4. Its gradient is the sum of d sigma over all samples, and d sigma comes out of the
-    #     composite backward's suffix sums sum_{k>i} g_k w_k - cancellation-prone, scanned in fp32 by wave shuffles here and by
-    #     torch's double-accumulating cumsum / cumprod in the reference: measured 1.1e-4 (coarse, D8 W256)
-    #     where the reference's own spread happens to be 6e-6.
+    # reference's fp32 gradient within 2 x that + eps, eps = 2e-6 (sin/cos, MFMA summation order) for EVERY parameter.
+    # (Rounds 3-4 granted alpha_linear.* 3e-4: the composite backward's suffix sums sum_{k>i} g_k w_k were scanned in fp32 where
+    # torch's CPU cumsum accumulates in double. Round 5: composite_bwd.hip scans in double; the exception is gone.)
     ref = O.train_step_grads(rays, sc, sf, target, t_rand=g[tag + '_t_rand'], u=g[tag + '_u'], D=D, W=W)
     worst, lines = 0.0, []
     for nm, net in (('coarse', coarse), ('fine', fine)):
@@ -80,7 +78,7 @@ def test_training_step_gradients(golden, tag, D, W):
             got = N(p.grad)
             e = l2_err(got, g['%s_%s_grad_%s' % (tag, nm, k)])                      # vs the reference's autograd (fp32), whole tensor
             spread = float(g['%s_%s_referr_%s' % (tag, nm, k)])
-            bound = 2 * spread + (3e-4 if k.startswith('alpha_linear') else 2e-6)
+            bound = 2 * spread + 2e-6
             worst = max(worst, e / bound)
             lines.append('%-6s %-26s err %.2e  reference fp32-vs-fp64 %.2e  bound %.2e' % (nm, k, e, spread, bound))
             assert l2_err(got, ref['grads_' + nm][k]) < 5e-3, (nm, k)              # and the float64-backward oracle, loosely
