@@ -121,3 +121,44 @@ def l2_err(a, b):
     b = np.asarray(b, np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def trained_pair_inputs(g):
+    """Fixture g21 (a pair TRAINED and rendered by the reference, tests/golden/make_golden.py g21): state dicts, the 4 096 rays
+    and the perturbed pass's draws - regenerated from the stored seed exactly as the generator drew them."""
+    sc = {k[len('coarse_'):]: g[k] for k in g if k.startswith('coarse_')}
+    sf = {k[len('fine_'):]: g[k] for k in g if k.startswith('fine_')}
+    rays = g['rays']
+    rs = np.random.RandomState(int(g['draw_seed']))
+    t_rand = rs.uniform(size=(rays.shape[0], 64)).astype(np.float32)
+    u = rs.uniform(size=(rays.shape[0], 128)).astype(np.float32)
+    return sc, sf, rays, t_rand, u
+
+
+def check_against_trained_reference(g, tag, got, who):
+    """`got` = render_rays outputs of an implementation on g21's rays; `tag` = 'det' | 'pert'. The yardstick is the REFERENCE:
+      * coarse pass (rgb0 / acc0 / disp0: nothing resampled in between): within 1e-4 of the reference's fp32 on EVERY ray;
+      * whole path: on a trained (sharp) density a coarse weight that moves in its 6th digit can move an importance sample
+        across a bin (RH:226-240), so single rays differ by 1e-3 between ANY two correct implementations - the reference's own
+        fp32 and fp64 runs included: g21 stores how many of the 4 096 rays THEY disagree on beyond 1e-4 (rgb or acc). An
+        implementation may disagree with the reference's fp32 on at most 2x that many + 4 rays, the median hit ray within 1e-6,
+        and where it does disagree it must be a bin flip, not garbage: it stays within 3x the reference pair's worst ray."""
+    lines = []
+    for k in ('rgb0', 'acc0', 'disp0'):
+        e = rel_err(got[k], g['%s_%s' % (tag, k)])
+        lines.append('%s %s coarse %-5s rel err %.1e' % (who, tag, k, e))
+        assert e < 1e-4, lines
+    d = np.abs(np.asarray(got['rgb_map'], np.float64) - g[tag + '_rgb_map']).max(1)
+    da = np.abs(np.asarray(got['acc_map'], np.float64) - g[tag + '_acc_map'])
+    over = int(((d > 1e-4) | (da > 1e-4)).sum())
+    ref_over, ref_max = int(g[tag + '_ref_rays_over_1e-4']), float(g[tag + '_ref_max_abs'])
+    hit = g[tag + '_acc_map'] > 0.5
+    med = float(np.median(d[hit]))
+    worst = float(max(d.max(), da.max()))
+    lines.append('%s %s whole path: %d of %d rays beyond 1e-4 (reference fp32 vs its own fp64: %d), median hit ray %.1e, worst %.1e '
+                 '(reference pair: %.1e)' % (who, tag, over, d.size, ref_over, med, worst, ref_max))
+    print('\n'.join(lines))
+    assert over <= 2 * ref_over + 4, lines
+    assert med < 1e-6, lines
+    assert worst <= max(3 * ref_max, 1e-4), lines
+    return over, med, worst

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import synth
-from conftest import rel_err, plain_rel_err
+from conftest import rel_err, plain_rel_err, trained_pair_inputs, check_against_trained_reference
 from hiputil import T, N, hip_nerf, dev
 from oracle import nerf as O
 
@@ -458,3 +458,30 @@ def test_points_formed_inside_the_kernel_equal_the_point_tensor_form():
     out_r = RN._composite(a, z, rays, None, True, None, True)
     for u, v in zip(out_p, out_r):
         assert torch.equal(u.view(torch.int32), v.view(torch.int32))
+
+
+def test_render_rays_on_a_pair_trained_by_the_reference(golden):
+    """every other reference-held fixture uses seeded random-init networks (flat densities, no importance
+    bin ever flips). g21 is a D=4 W=64 coarse + fine pair the REFERENCE trained for 2 000 of its own steps (RN:776-801) on the
+    analytic sphere and then rendered itself on 4 096 rays, deterministic and perturbed, in fp32 and in fp64. The HIP path
+    is held to the reference's fp32 outputs: the coarse pass on every ray, the whole path up to the number of rays the
+    reference's own two precisions disagree on (conftest.check_against_trained_reference)."""
+    from nerfail_amd import nerf_to_coord as NC
+    from nerfail_amd.run_nerf_helpers import NeRF
+    g = golden('g21_trained_pair')
+    sc, sf, rays, t_rand, u = trained_pair_inputs(g)
+
+    def net(sd):
+        m = NeRF(D=4, W=64, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.requires_grad_(False).to(dev())
+    coarse, fine = net(sc), net(sf)
+    with torch.no_grad():
+        r = NC.render_rays(T(rays), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True)
+        rp = NC.render_rays(T(rays), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.,
+                            t_rand=T(t_rand), u=T(u))
+    check_against_trained_reference(g, 'det', {k: N(v) for k, v in r.items()}, 'HIP')
+    check_against_trained_reference(g, 'pert', {k: N(v) for k, v in rp.items()}, 'HIP')
+    # the argmax point (NC:418-423) on the rays where nothing flipped: the same sample, hence the same point
+    same = np.abs(N(r['rgb_map']) - g['det_rgb_map']).max(1) < 1e-5
+    assert rel_err(N(r['pts_max'])[same], g['det_pts_max'][same]) < 1e-4

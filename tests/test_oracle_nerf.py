@@ -2,7 +2,7 @@
 import numpy as np
 
 import synth
-from conftest import rel_err, l2_err
+from conftest import rel_err, l2_err, trained_pair_inputs, check_against_trained_reference
 from oracle import nerf as O
 
 
@@ -199,3 +199,17 @@ def test_torch_port_matches_reference_training_step(golden):
                 else:
                     refn = float(g['full_%s_gradnorm_%s' % (nm, k)])
                     assert abs(np.linalg.norm(got.astype(np.float64)) - refn) < 1e-4 * refn, (nm, k)
+
+
+def test_oracle_on_a_pair_trained_by_the_reference(golden):
+    """the oracle on TRAINED weights (sharp density, importance bins that flip), judged by the reference's
+    own render_rays outputs and the reference's own fp32-vs-fp64 disagreement (fixture g21)."""
+    g = golden('g21_trained_pair')
+    sc, sf, rays, t_rand, u = trained_pair_inputs(g)
+    assert int(g['steps']) >= 2000 and float(g['loss_last']) < 0.05 * float(g['loss_first'])     # it really learned the scene
+    n = 1024                                                           # (the numpy oracle at D=4 W=64: ~1 s per 1024 rays)
+    sub = {k: (v[:n] if getattr(v, 'shape', ()) and v.shape[:1] == (4096,) else v) for k, v in g.items()}
+    r = O.render_rays(rays[:n], sc, 64, 128, sf, white_bkgd=True, D=4, W=64)
+    check_against_trained_reference(sub, 'det', r, 'oracle')
+    r = O.render_rays(rays[:n], sc, 64, 128, sf, white_bkgd=True, D=4, W=64, t_rand=t_rand[:n], u=u[:n])
+    check_against_trained_reference(sub, 'pert', r, 'oracle')
