@@ -207,6 +207,12 @@ int nerfail_composite(const float* raw, const float* z_vals, const float* rays, 
                       float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
                       const float* pts, float* pts_max, void* stream);
 
+/* Which kernel serves nerfail_composite: 0 = automatic (default: two rays per wave when n_samples is a multiple of 32, else
+ * one ray per wave), 1 = one ray per wave everywhere. The two forms add a ray's sums in different orders (last bits). The
+ * initial value is read ONCE from NERFAIL_COMPOSITE_KERNEL ("1"); the switch exists for A/B timing and for the parity test of
+ * one form against the other. Process-wide; returns the previous value. */
+int nerfail_composite_select(int which);
+
 /* Backward of raw2outputs (autograd of RN:262-305, what loss.backward() at RN:791 needs): given the upstream
  * gradients of rgb_map[R,3], disp_map[R], acc_map[R], depth_map[R], weights[R,N] (each may be NULL = zero)
  * writes d_raw[R,N,4]. z_vals / rays_d receive no gradient (z_samples is detached, RN:394). */

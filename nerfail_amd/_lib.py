@@ -72,6 +72,7 @@ SIGNATURES = {
     'nerfail_mlp_bwd_weights': (c_i, [c_i, c_i, c_i, c_p, c_p, c_i64, ctypes.POINTER(MlpParams), c_i64, ctypes.POINTER(MlpParams),
                                       c_i, c_p, ctypes.c_size_t, c_p]),
     'nerfail_composite': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'nerfail_composite_select': (c_i, [c_i]),
     'nerfail_composite_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_knn8': (c_i, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
     'nerfail_knn8_grid_workspace_bytes': (ctypes.c_size_t, [c_i64]),

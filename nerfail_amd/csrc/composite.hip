@@ -255,6 +255,21 @@ __global__ __launch_bounds__(256) void composite2_kernel(
 
 using namespace nerfail;
 
+// 0 = automatic (two rays per wave for multiples of 32 samples), 1 = the one-ray-per-wave form everywhere. Initialised ONCE
+// from NERFAIL_COMPOSITE_KERNEL (getenv per call races with setenv from other threads); tests and A/B runs switch
+// it through nerfail_composite_select.
+static int composite_select_from_env() {
+    const char* sel = getenv("NERFAIL_COMPOSITE_KERNEL");
+    return (sel != nullptr && sel[0] == '1') ? 1 : 0;
+}
+static int g_composite_select = composite_select_from_env();
+
+extern "C" int nerfail_composite_select(int which) {
+    const int prev = g_composite_select;
+    if (which == 0 || which == 1) g_composite_select = which;
+    return prev;
+}
+
 extern "C" int nerfail_composite(const float* raw, const float* z_vals, const float* rays, const float* noise,
                                  int64_t n_rays, int n_samples, int white_bkgd, float* rgb_map, float* disp_map,
                                  float* acc_map, float* weights, float* depth_map, const float* pts, float* pts_max,
@@ -266,8 +281,7 @@ extern "C" int nerfail_composite(const float* raw, const float* z_vals, const fl
     NF_REQUIRE(rgb_map != nullptr && disp_map != nullptr && acc_map != nullptr, "rgb_map / disp_map / acc_map is NULL");
     NF_REQUIRE(pts == nullptr || pts_max != nullptr, "pts is only read for pts_max");
     hipStream_t s = as_stream(stream);
-    const char* sel = getenv("NERFAIL_COMPOSITE_KERNEL");            // "1": the one-ray-per-wave form (A/B runs, tests); read per call
-    const bool one_ray_form = sel != nullptr && sel[0] == '1';
+    const bool one_ray_form = g_composite_select == 1;
     if (n_samples % 32 == 0 && !one_ray_form) {              // two rays per wave (64, 192 and every other multiple of 32)
         const dim3 block2(256), grid2((unsigned)((n_rays + 7) / 8));
 #define NF_COMPOSITE2(IPL)                                                                                                \
@@ -276,7 +290,8 @@ extern "C" int nerfail_composite(const float* raw, const float* z_vals, const fl
         switch (n_samples / 32) {
             case 1: NF_COMPOSITE2(1); break;  case 2: NF_COMPOSITE2(2); break;  case 3: NF_COMPOSITE2(3); break;
             case 4: NF_COMPOSITE2(4); break;  case 5: NF_COMPOSITE2(5); break;  case 6: NF_COMPOSITE2(6); break;
-            case 7: NF_COMPOSITE2(7); break;  default: NF_COMPOSITE2(8); break;
+            case 7: NF_COMPOSITE2(7); break;  case 8: NF_COMPOSITE2(8); break;
+            default: set_error("nerfail_composite: n_samples not covered by the two-ray kernel"); return NERFAIL_EINVAL;
         }
 #undef NF_COMPOSITE2
         NF_LAUNCHED("composite2_kernel");

@@ -154,11 +154,12 @@ __global__ __launch_bounds__(256) void gauss_fwd_views_kernel(const float4* __re
             const int last = (int)Ns - 1;     // (the launcher checks Ns < 2^31)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {     // issue all 8 gathers before using any
-                // .type(torch.long): truncation (GN:62). Through int32 (round 4): v_cvt_i32_f32 truncates, saturates and turns
-                // NaN into 0 in ONE instruction - after the clamp the same row as the 64-bit conversion picks for every
-                // float, which cost ~10 vector instructions per index (80 of this kernel's 286 per wave)
-                int j = (int)fi[k];
-                j = j < 0 ? 0 : (j > last ? last : j);
+                // .type(torch.long): truncation (GN:62). Through int32 (round 4; the 64-bit conversion cost ~10 vector instructions
+                // per index, 80 of this kernel's 286 per wave). The value is clamped to [0, Ns-1] AS A FLOAT first (v_med3_f32;
+                // NaN -> 0), so the conversion itself is always in range - an out-of-range float -> int conversion is undefined in
+                // C++ and the in-bounds guarantee of the gather must not rest on it. Same row as before for every float.
+                int j = (int)__builtin_amdgcn_fmed3f(fi[k], 0.f, (float)last);
+                j = j > last ? last : j;      // ((float)last may round up)
                 rows[k] = spatial[j];         // unconditional: a per-gather "skip if w == 0" branch serialises the 8 loads
             }
         }

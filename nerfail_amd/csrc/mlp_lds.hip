@@ -31,6 +31,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 
+#ifndef NF_LDS_SPREAD
+#define NF_LDS_SPREAD 0     // 1: one piece of side work per MFMA shadow (WRing::step)
+#endif
 #ifndef NF_LDS_GPM
 #define NF_LDS_GPM 4        // pieces per ring group = NF_LDS_GPM * NT (4: one barrier per 4 quads of a W-wide layer)
 #endif
@@ -147,6 +150,32 @@ struct WRing {
         __builtin_amdgcn_sched_barrier(0);
         pre();
         int k = 0;
+        if constexpr (NF_LDS_SPREAD && HSP == 4 && C::HS == 4) {
+            // Round 5: ONE piece of side work per MFMA shadow. The round-2 form put the whole prefetch (address arithmetic + four
+            // ds_read_b128) and the next quad's operand preparation behind MFMA 3: ten-odd instructions whose issue takes longer
+            // than the 64 cycles MFMA 4 needs the pipe for, so MFMA 5 started late (measured: tools/lds_steps.py). Here every
+            // MFMA is pinned, tile-major (a dependent MFMA issues when its predecessor leaves the pipe), and its shadow carries at
+            // most one of: a refill DMA (SYNC steps: behind MFMAs 0..GPW-1), one fragment read of the next step, the operand
+            // preparation. The fragment reads start behind MFMA 3 at the earliest: the first use of `cur` is answered with
+            // s_waitcnt lgkmcnt(0), free only while no read of the NEXT step has been issued.
+            constexpr int R0 = SYNC ? (C::GPW > 4 ? C::GPW : 4) : 4;      // first MFMA whose shadow takes a fragment read
+            static_assert(R0 + 4 < 16, "fragment reads and operand preparation fit behind this step's MFMAs");
+#pragma unroll
+            for (int t = 0; t < HSP; ++t) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mf(t, e, cur[t][e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (SYNC && k < C::GPW) dma(k);
+                    post(k);
+                    if (k >= R0 && k < R0 + 4) fr[k - R0] = lds_read4(rl + (rd + (k - R0)) * kPiece);
+                    if (k == R0 + 4) mid();
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++k;
+                }
+            }
+
+        } else {
 #pragma unroll
         for (int t = 0; t < HSP; ++t) {
 #pragma unroll
@@ -165,6 +194,7 @@ struct WRing {
                 mid();
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         if (SYNC) {
 #pragma unroll

@@ -122,13 +122,15 @@ def test_raw2outputs(golden):
 
 
 @pytest.mark.parametrize('Ns', [32, 96, 128, 160, 192, 224, 256])
-def test_two_ray_composite_equals_one_ray_form_and_oracle(Ns, monkeypatch):
+def test_two_ray_composite_equals_one_ray_form_and_oracle(Ns):
     """Round 4: sample counts that are multiples of 32 run on composite2_kernel (two rays per wave, lane l of a half-wave owns
-    samples l, l + 32, ...: coalesced, block-wise transmittance scan); every other count - and NERFAIL_COMPOSITE_KERNEL=1 - on
+    samples l, l + 32, ...: coalesced, block-wise transmittance scan); every other count - and nerfail_composite_select(1) - on
     the one-ray-per-wave kernel. Same per-sample arithmetic, ray sums in another order: the two forms agree to rounding on
     every output incl. the argmax point (odd ray counts: the idle half-wave of the last wave; noise; both backgrounds; the
     point tensor given or formed from the ray), and both agree with the oracle."""
     from nerfail_amd.run_nerf import _composite
+    from nerfail_amd import _lib
+    lib = _lib.load()
     rs = np.random.RandomState(Ns)
     for R in (1, 5, 64):
         z = np.sort(rs.uniform(2, 6, (R, Ns)).astype(np.float32), -1)
@@ -140,9 +142,12 @@ def test_two_ray_composite_equals_one_ray_form_and_oracle(Ns, monkeypatch):
         for wb, nz, with_pts in ((True, None, False), (False, noise, True)):
             outs = {}
             for form in ('2', '1'):
-                monkeypatch.setenv('NERFAIL_COMPOSITE_KERNEL', form)
-                outs[form] = [N(t) for t in _composite(T(raw), T(z), T(rays), T(nz) if nz is not None else None, wb,
-                                                       T(pts) if with_pts else None, True)]
+                prev = lib.nerfail_composite_select(1 if form == '1' else 0)
+                try:
+                    outs[form] = [N(t) for t in _composite(T(raw), T(z), T(rays), T(nz) if nz is not None else None, wb,
+                                                           T(pts) if with_pts else None, True)]
+                finally:
+                    lib.nerfail_composite_select(prev)
             ref = O.raw2outputs(raw, z, rays[:, 3:6], nz, wb)
             for k, a, b, r in zip(('rgb', 'disp', 'acc', 'weights', 'depth'), outs['2'], outs['1'], ref):
                 assert rel_err(a, b) < 2e-6, (Ns, R, wb, k)                       # the two forms: summation order only

@@ -17,6 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nerfail_amd import build as B  # noqa: E402
 
+# shader-clock stamp at the start of EVERY step, kept in the 64 lanes of one VGPR (v_writelane-like select: no memory traffic);
+# dumped at kernel end: raw[(block*4 + wave)*66 + lane] = stamp of step (idx - 64 + lane), [64] = idx
+LDS_STEPS = [
+    ('    f32x4 fr[C::HS];         // fragments of the NEXT step',
+     '    unsigned st_v = 0; int st_i = 0;\n    f32x4 fr[C::HS];         // fragments of the NEXT step'),
+    ('        pre();\n        int k = 0;\n',
+     '        pre();\n        { const unsigned st_t = (unsigned)clock64(); st_v = ((int)(threadIdx.x & 63) == (st_i & 63) && st_i >= NF_ST_LO && st_i < NF_ST_LO + 64) ? st_t : st_v; ++st_i; }\n        int k = 0;\n'),
+    ('    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight',
+     '    { unsigned* o_ = reinterpret_cast<unsigned*>(a.raw) + (blockIdx.x * 4 + wave) * 66; o_[lane] = st.st_v; if (lane == 0) o_[64] = st.st_i; }\n'
+     '    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight')]
+
 # name -> (source file, [(old, new), ...], extra compiler flags)
 EXPERIMENTS = {
     # round 4, K11: the per-wave LDS slice doubled = half the waves per CU (how much does the segmented reduce depend on occupancy?)
@@ -57,16 +68,11 @@ EXPERIMENTS = {
                                     '        for (int t = 0; t < C::HS; ++t) asm volatile("" : "+v"(fr[t]));\n    }\n    __device__ __forceinline__ void start()')], []),
     # shader-clock stamp at the end of EVERY step, kept in the 64 lanes of one VGPR (v_writelane: no memory traffic);
     # dumped at kernel end: raw[(block*4 + wave)*66 + lane] = stamp of step (idx - 64 + lane), [64] = idx
-    'lds_steps': ('mlp_lds.hip', [
-        ('    f32x4 fr[C::HS];         // fragments of the NEXT step',
-         '    unsigned st_v = 0; int st_i = 0;\n    f32x4 fr[C::HS];         // fragments of the NEXT step'),
-        ('        pre();\n        int k = 0;\n', '        pre();\n        const unsigned st_t = (unsigned)clock64();\n        int k = 0;\n'),
-        ('            if (t == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n',
-         '            if (t == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n'
-         '                st_v = ((int)(threadIdx.x & 63) == (st_i & 63)) ? st_t : st_v; ++st_i;\n'),
-        ('    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight',
-         '    { unsigned* o_ = reinterpret_cast<unsigned*>(a.raw) + (blockIdx.x * 4 + wave) * 66; o_[lane] = st.st_v; if (lane == 0) o_[64] = st.st_i; }\n'
-         '    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight')], []),
+    'lds_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27776']),          # the last 64 steps of the last of 48 tiles (8192 x 192 samples)
+    'lds_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27340']),       # tile 47, steps 80..143 = pts_linears[2]
+    'lds_spread_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27340']),
+    'lds_spread': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=1']),
+    'lds_spread_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27776']),
     'lds_emajor': ('mlp_lds.hip', [
         ('        for (int t = 0; t < HSP; ++t) {\n#pragma unroll\n            for (int e = 0; e < 4; ++e) {\n                mf(t, e, cur[t][e]);',
          '        for (int e = 0; e < 4; ++e) {\n#pragma unroll\n            for (int t = 0; t < HSP; ++t) {\n                mf(t, e, cur[t][e]);'),

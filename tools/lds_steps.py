@@ -29,10 +29,11 @@ torch.cuda.synchronize()
 w = raw.reshape(-1).view(torch.int32)[:1024 * 66].reshape(1024, 66).cpu().numpy().astype(np.int64) & 0xffffffff
 idx = int(w[0, 64])
 print('steps per wave:', idx, '(580 per tile)')
-order = [(idx + k) % 64 for k in range(64)]            # oldest .. newest
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else idx - 64      # first recorded step (the build's NF_ST_LO)
+order = [(lo + k) % 64 for k in range(64)]             # oldest .. newest
 t = w[:, order]
 d = np.diff(t, axis=1) & 0xffffffff
 med = np.median(d, axis=0)
-first = idx - 64
+first = lo
 print(' '.join('%d:%.0f' % ((first + 1 + k) % 580, v) for k, v in enumerate(med)))
 print('mean of the 63 steps: %.0f cycles (1024 = 16 MFMAs at pipe rate)' % med.mean())
