@@ -32,7 +32,13 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 
 #ifndef NF_LDS_SPREAD
-#define NF_LDS_SPREAD 0     // 1: one piece of side work per MFMA shadow (WRing::step)
+#define NF_LDS_SPREAD 1     // 1: one piece of side work per MFMA shadow (WRing::step, inference kernels); 0: round-2 form
+#endif
+#ifndef NF_LDS_DMA_BUF
+#define NF_LDS_DMA_BUF 1    // 1: LDS-DMA as buffer_load_dwordx4 ... lds (SGPR base + SGPR piece offset + one 32-bit lane offset)
+#endif                      //    0: global_load_lds_dwordx4 (a 64-bit address pair per lane)
+#ifndef NF_LDS_DMA_SPREAD
+#define NF_LDS_DMA_SPREAD 1 // 1: one refill DMA per step, spread over the group interval (W = 256 only; LdsCfg::kDmaSpread)
 #endif
 #ifndef NF_LDS_GPM
 #define NF_LDS_GPM 4        // pieces per ring group = NF_LDS_GPM * NT (4: one barrier per 4 quads of a W-wide layer)
@@ -59,13 +65,29 @@ struct LdsCfg {
     static_assert(GP % 4 == 0 && RP % GP == 0 && S >= 3, "ring geometry");
     static_assert((S - 2) * GPW <= 48, "vmcnt is a 6-bit counter");
     static_assert(GPW <= 8 && (GPW % 4 == 0 || GPW < 4), "dma() covers 8 pieces per wave and group, in blocks of 4");
+    // Round 5: the refill of a freed ring slot is spread over the whole group interval - ONE LDS-DMA per wave and step instead
+    // of the group's GPW DMAs in a burst behind the first MFMAs of the boundary step. Per-step clock stamps (tools/lds_steps.py)
+    // showed the boundary step 180-400 cycles over its 1024 and an ordinary step with the DMAs removed: with the four waves of
+    // the workgroup each issuing 8 KB at the same moment the vector-memory path backs up and a DMA's issue outlasts the 64
+    // cycles of the MFMA it stands behind. Needs every part of the net to run HS-piece steps (W = 256: 8 and 4 out tiles),
+    // so that "step j of the interval" is a compile-time position everywhere in the stream.
+    static constexpr bool kDmaSpread = NF_LDS_DMA_SPREAD && NT == 8 && HS == 4 && (GP / HS) == GPW;
+    static constexpr int SPG = GP / HS;                         // steps per group (full-width steps)
 };
 
 // The weight stream of one workgroup. Every member but fr / gsrc / rl is wave-uniform (SGPRs).
-template <int NT>
+// SP1: the step form with ONE piece of side work per MFMA shadow (round 5; inference kernels - the training kernel's stores
+// already fill those shadows and it spills under this form).
+template <int NT, bool SP1 = false, bool NEWDMA = false>
 struct WRing {
     using C = LdsCfg<NT>;
+    // NEWDMA (round 5, inference kernels): the refill as buffer_load ... lds, one DMA per step (LdsCfg::kDmaSpread). The training
+    // kernel keeps the round-2 form (global_load_lds in a burst behind the boundary step): under the new form it spills.
+    static constexpr bool kBufDma = NEWDMA && NF_LDS_DMA_BUF;
+    static constexpr bool kSpreadDma = NEWDMA && C::kDmaSpread;
     const float* gsrc;       // packed + lane*4: this lane's 16 bytes of stream piece 0
+    __amdgpu_buffer_rsrc_t rsrc;   // the packed image as a raw buffer (NF_LDS_DMA_BUF)
+    int voff;                // lane * 16: this lane's byte offset inside a piece
     float* ring;             // LDS ring base
     const float* rl;         // ring + lane*4
     int total;               // stream length in pieces (multiple of GP)
@@ -83,8 +105,13 @@ struct WRing {
     __device__ __forceinline__ void dma_at() const {
         constexpr int B4 = I / 4;                                // which block of 4 pieces (one base each)
         const int first = wave * C::GPW + 4 * B4;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + first) * kPiece),
-                                         (lds_void_t*)(ring + (slot * C::GP + first) * kPiece), 16, (I % 4) * kPiece * 4, 0);
+        if constexpr (kBufDma) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(ring + (slot * C::GP + first) * kPiece), 16, voff,
+                                                     (src + first) * (kPiece * 4), (I % 4) * kPiece * 4, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + first) * kPiece),
+                                             (lds_void_t*)(ring + (slot * C::GP + first) * kPiece), 16, (I % 4) * kPiece * 4, 0);
+        }
     }
     __device__ __forceinline__ void dma(int i) const {           // i is a constant after unrolling
         switch (i) {
@@ -123,9 +150,13 @@ struct WRing {
             group_issued();
         }
         boundary();
+        if constexpr (kSpreadDma) {
+            dma(0);                  // the state right behind a boundary step: DMA 0 of the next group issued, 1.. follow step by step
+        } else {
 #pragma unroll
-        for (int i = 0; i < C::GPW; ++i) dma(i);
-        group_issued();
+            for (int i = 0; i < C::GPW; ++i) dma(i);
+            group_issued();
+        }
         prefetch();
     }
     // One step: consume HSP pieces (out tiles) x 4 k-steps; mf(t, e, a) issues the MFMA of tile t, k-step e with A
@@ -139,8 +170,13 @@ struct WRing {
     // (work for LATER steps: the next quad's B operands).
     // post(k) runs behind MFMA k of the step (training: ONE activation store per MFMA - four stores issued back to back
     // drained the matrix pipe: a global store takes about as long to issue as an MFMA runs).
+    // J (kDmaSpread): position of this step in the refill interval that began at the last boundary (0 = the SYNC step itself):
+    // it issues DMA J of the group, the interval's last step closes the group.
+    // (J is a constant after unrolling, like dma()'s argument.)
     template <int HSP, bool SYNC, int EXTRA = 0, class PRE, class MID, class MF, class POST>
-    __device__ __forceinline__ void step(PRE&& pre, MID&& mid, MF&& mf, POST&& post) {
+    __device__ __forceinline__ void step(const int J, PRE&& pre, MID&& mid, MF&& mf, POST&& post) {
+        constexpr bool SPREAD = kSpreadDma;
+        static_assert(!SPREAD || HSP == C::HS, "spread refill: full-width steps");
         f32x4 cur[HSP];
 #pragma unroll
         for (int t = 0; t < HSP; ++t) cur[t] = fr[t];
@@ -150,7 +186,7 @@ struct WRing {
         __builtin_amdgcn_sched_barrier(0);
         pre();
         int k = 0;
-        if constexpr (NF_LDS_SPREAD && HSP == 4 && C::HS == 4) {
+        if constexpr (SP1 && HSP == 4 && C::HS == 4) {
             // Round 5: ONE piece of side work per MFMA shadow. The round-2 form put the whole prefetch (address arithmetic + four
             // ds_read_b128) and the next quad's operand preparation behind MFMA 3: ten-odd instructions whose issue takes longer
             // than the 64 cycles MFMA 4 needs the pipe for, so MFMA 5 started late (measured: tools/lds_steps.py). Here every
@@ -158,7 +194,7 @@ struct WRing {
             // most one of: a refill DMA (SYNC steps: behind MFMAs 0..GPW-1), one fragment read of the next step, the operand
             // preparation. The fragment reads start behind MFMA 3 at the earliest: the first use of `cur` is answered with
             // s_waitcnt lgkmcnt(0), free only while no read of the NEXT step has been issued.
-            constexpr int R0 = SYNC ? (C::GPW > 4 ? C::GPW : 4) : 4;      // first MFMA whose shadow takes a fragment read
+            constexpr int R0 = (SYNC && !SPREAD) ? (C::GPW > 4 ? C::GPW : 4) : 4;      // first MFMA whose shadow takes a fragment read
             static_assert(R0 + 4 < 16, "fragment reads and operand preparation fit behind this step's MFMAs");
 #pragma unroll
             for (int t = 0; t < HSP; ++t) {
@@ -166,10 +202,10 @@ struct WRing {
                 for (int e = 0; e < 4; ++e) {
                     mf(t, e, cur[t][e]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (SYNC && k < C::GPW) dma(k);
+                    if (SPREAD ? k == 0 : (SYNC && k < C::GPW)) dma(SPREAD ? J : k);
                     post(k);
                     if (k >= R0 && k < R0 + 4) fr[k - R0] = lds_read4(rl + (rd + (k - R0)) * kPiece);
-                    if (k == R0 + 4) mid();
+                    if (k == R0 + 4) mid(-1);
                     __builtin_amdgcn_sched_barrier(0);
                     ++k;
                 }
@@ -181,22 +217,38 @@ struct WRing {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 mf(t, e, cur[t][e]);
-                if (SYNC && k < C::GPW) {        // one refill DMA behind each of the first MFMAs
-                    dma(k);
+                if (SPREAD ? k == 0 : (SYNC && k < C::GPW)) {   // burst form: one refill DMA behind each of the first MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma(SPREAD ? J : k);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 post(k);
                 ++k;
             }
-            if (t == 0) {
+            if (NF_LDS_SPREAD == 2 && HSP == 4 && C::HS == 4) {     // the prefetch in two halves: behind tile 0 and behind tile 1
+                if (t == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    fr[0] = lds_read4(rl + (rd + 0) * kPiece);
+                    fr[1] = lds_read4(rl + (rd + 1) * kPiece);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (t == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    fr[2] = lds_read4(rl + (rd + 2) * kPiece);
+                    fr[3] = lds_read4(rl + (rd + 3) * kPiece);
+                    mid(-1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (t == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 prefetch();
-                mid();
+                mid(-1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         }
-        if (SYNC) {
+        if constexpr (SPREAD) {
+            if (J == C::SPG - 1) group_issued();
+        } else if (SYNC) {
 #pragma unroll
             for (int i = 4 * HSP; i < C::GPW; ++i) dma(i);
             group_issued();
@@ -204,11 +256,15 @@ struct WRing {
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int HSP, bool SYNC>
-    __device__ __forceinline__ void skip() {                     // padding pieces: no MFMAs
+    __device__ __forceinline__ void skip(const int J) {          // padding pieces: no MFMAs
         rd += HSP;
         if (rd >= C::RP) rd = 0;
-        if (SYNC) {
-            boundary();
+        if (SYNC) boundary();
+        if constexpr (kSpreadDma) {
+            static_assert(HSP == C::HS, "spread refill: full-width steps");
+            dma(J);
+            if (J == C::SPG - 1) group_issued();
+        } else if (SYNC) {
 #pragma unroll
             for (int i = 0; i < C::GPW; ++i) dma(i);
             group_issued();
@@ -230,8 +286,8 @@ struct WRing {
 //                and a store issued there is old enough at the next group boundary (the boundary's counted vmcnt leaves
 //                only the 8 youngest vector-memory operations in flight; stores count like LDS-DMAs, in order).
 struct NoStore { __device__ __forceinline__ void operator()(int, int, const float (&)[4]) const {} };
-template <int NT, int OT, int NQ, int PAD, int NIN, class Hook, class BPrep, class TStore = NoStore>
-__device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook hook, BPrep bprep, TStore tstore = TStore()) {
+template <int NT, int OT, int NQ, int PAD, int NIN, class Ring, class Hook, class BPrep, class TStore = NoStore>
+__device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook, BPrep bprep, TStore tstore = TStore()) {
     using C = LdsCfg<NT>;
     constexpr int HSP = OT >= 4 ? 4 : OT, SPQ = OT / HSP;
     static_assert((NQ * OT + PAD) % C::GP == 0, "a part is a whole number of ring groups");
@@ -246,7 +302,16 @@ __device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook
                 acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[q][e], acc[sp * HSP + t], 0, 0, 0);
             };
             auto pr = [&]() { if (sp == 0) hook(q); };
-            auto mid = [&]() { if (sp == SPQ - 1 && q + 1 < NQ) bprep(q + 1, bq[q + 1]); };
+            auto mid = [&](int e) {                                  // e < 0: all four operands of the next quad; else operand e only
+                if (sp == SPQ - 1 && q + 1 < NQ) {
+                    if (e < 0) bprep(q + 1, bq[q + 1]);
+                    else {
+                        float tmp[4];                                // (the three unused elements are dead code after inlining)
+                        bprep(q + 1, tmp);
+                        bq[q + 1][e] = tmp[e];
+                    }
+                }
+            };
             constexpr int K0 = 4 * HSP >= 8 ? 4 : 0;                 // behind MFMAs 4..7 (a one-tile step has only 0..3)
             auto post = [&](int k) {
                 if constexpr (!std::is_same<TStore, NoStore>::value) {
@@ -272,15 +337,17 @@ __device__ __forceinline__ void lds_part(WRing<NT>& st, f32x16 (&acc)[NIN], Hook
             // acknowledged - free in practice), so that never a DMA of the group about to be read is still outstanding.
             constexpr int EXTRA = std::is_same<TStore, NoStore>::value ? 0 : 4 * (C::GP / OT - (SPQ == 1 ? 1 : 0));
             static_assert(EXTRA >= 0, "a store-carrying part spans at least one quad per group");
-            if (done % C::GP == 0) st.template step<HSP, true, EXTRA>(pr, mid, mf, post);
-            else st.template step<HSP, false>(pr, mid, mf, post);
+            const int J = Ring::kSpreadDma ? (done / HSP) % C::SPG : 0;        // (done / HSP - 1 is this step's index in the part)
+            if (done % C::GP == 0) st.template step<HSP, true, EXTRA>(J, pr, mid, mf, post);
+            else st.template step<HSP, false>(J, pr, mid, mf, post);
         }
     }
 #pragma unroll
     for (int p = 0; p < PAD / HSP; ++p) {
         const int done = NQ * OT + (p + 1) * HSP;
-        if (done % C::GP == 0) st.template skip<HSP, true>();
-        else st.template skip<HSP, false>();
+        const int J = Ring::kSpreadDma ? (done / HSP) % C::SPG : 0;
+        if (done % C::GP == 0) st.template skip<HSP, true>(J);
+        else st.template skip<HSP, false>(J);
     }
 }
 
@@ -356,8 +423,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
     const float* const c_alpha = cst + (L.alpha_off - L.b_off[0]);
     const float* const c_rgb = cst + (L.rgb_off - L.b_off[0]);
 
-    WRing<NT> st;
+    WRing<NT, NF_LDS_SPREAD == 1 && !TRAIN, !TRAIN> st;
     st.gsrc = a.packed + lane * 4; st.ring = ring0; st.rl = ring0 + lane * 4;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, (int)(L.w_total * 4), 0x00020000);   // raw buffer: the weight range
+    st.voff = lane * 16;
     st.total = (int)(L.w_total / kPiece); st.src = 0; st.slot = 0; st.rd = 0; st.wave = wave;
     st.start();
 

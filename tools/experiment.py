@@ -38,9 +38,12 @@ EXPERIMENTS = {
     'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, hh, emb, demb);\n',
                                    '        for (int i_ = 0; i_ < 4 * kEmbQuads; ++i_) emb[i_] = 0.25f * (float)(lane & 3) + (float)s * 1e-9f;\n'
                                    '        for (int i_ = 0; i_ < 4 * kDirQuads; ++i_) demb[i_] = 0.5f;\n')], []),
-    'lds_nodma': ('mlp_lds.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(gsrc + (size_t)(src + first) * kPiece),\n'
-                                   '                                         (lds_void_t*)(ring + (slot * C::GP + first) * kPiece), 16, (I % 4) * kPiece * 4, 0);\n',
-                                   '        asm volatile("" :: "s"(first));\n')], []),
+    'lds_nodma': ('mlp_lds.hip', [('            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(ring + (slot * C::GP + first) * kPiece), 16, voff,\n'
+                                   '                                                     (src + first) * (kPiece * 4), (I % 4) * kPiece * 4, 0);\n',
+                                   '            asm volatile("" :: "s"(first));\n')], []),
+    'lds_dma_global': ('mlp_lds.hip', [], ['-DNF_LDS_DMA_BUF=0']),
+    'lds_dma_burst': ('mlp_lds.hip', [], ['-DNF_LDS_DMA_SPREAD=0']),
+    'lds_dma_global_burst': ('mlp_lds.hip', [], ['-DNF_LDS_DMA_BUF=0', '-DNF_LDS_DMA_SPREAD=0']),
     'lds_nobarrier': ('mlp_lds.hip', [('        __builtin_amdgcn_s_barrier();\n        asm volatile("" ::: "memory");\n',
                                        '        asm volatile("" ::: "memory");\n')], []),
     # shader-clock stamps of one tile's phases -> raw[(block*4 + wave)] as 4 uint32 deltas (timing only, outputs destroyed)
@@ -71,7 +74,8 @@ EXPERIMENTS = {
     'lds_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27776']),          # the last 64 steps of the last of 48 tiles (8192 x 192 samples)
     'lds_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27340']),       # tile 47, steps 80..143 = pts_linears[2]
     'lds_spread_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27340']),
-    'lds_spread': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=1']),
+    'lds_spread0': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=0']),
+    'lds_spread2': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=2']),
     'lds_spread_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27776']),
     'lds_emajor': ('mlp_lds.hip', [
         ('        for (int t = 0; t < HSP; ++t) {\n#pragma unroll\n            for (int e = 0; e < 4; ++e) {\n                mf(t, e, cur[t][e]);',
