@@ -124,6 +124,12 @@ int nerfail_mlp_fwd(const float* packed, int D, int W, int skip, const float* pt
  * exists for A/B timing and for the parity test of one against the other. Process-wide; returns the previous value. */
 int nerfail_mlp_fwd_select(int which);
 
+/* Which kernel serves nerfail_mlp_bwd_data / nerfail_mlp_bwd_data2: 0 = automatic (default: the LDS-ring kernel for W = 256 and
+ * even depths <= 8, else the register-streamed one), 1 = register-streamed (mlp_bwd.hip), 2 = LDS ring (mlp_lds.hip; shapes it
+ * does not cover return NERFAIL_EINVAL). Both store the same bits; the switch exists for A/B timing and for the parity test of
+ * one against the other. Initial value from NERFAIL_BWD_KERNEL=reg|lds (read once). Process-wide; returns the previous value. */
+int nerfail_mlp_bwd_select(int which);
+
 /* NeRF.forward on an already embedded batch x[M, 63+27] (RH:100-123 as a standalone call). */
 int nerfail_mlp_fwd_embedded(const float* packed, int D, int W, int skip, const float* x, int64_t M,
                              float* raw, void* stream);

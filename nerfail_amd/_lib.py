@@ -52,6 +52,7 @@ SIGNATURES = {
     'nerfail_mlp_fwd': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
     'nerfail_mlp_fwd_rays': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
     'nerfail_mlp_fwd_select': (c_i, [c_i]),
+    'nerfail_mlp_bwd_select': (c_i, [c_i]),
     'nerfail_mlp_fwd_embedded': (c_i, [c_p, c_i, c_i, c_i, c_p, c_i64, c_p, c_p]),
     'nerfail_mlp_f16_image_bytes': (ctypes.c_size_t, [c_i, c_i, c_i]),
     'nerfail_mlp_pack_f16': (c_i, [ctypes.POINTER(MlpParams), c_p, c_p]),

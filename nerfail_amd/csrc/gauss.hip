@@ -109,6 +109,9 @@ __device__ __forceinline__ void fold_minmax(float emin, float emax, float* __res
 // Outputs besides x_rgba are optional: x (GN:83; the first element of gauss_net's return tuple) and, for the
 // rgb-gradient-only backward of the NeRFail-S step, alpha = x_3 / 255 plus the 3-bit pass mask (5 bytes per pixel
 // instead of re-reading x and ori: 32).
+#ifndef NF_K10_EARLY_INDEX
+#define NF_K10_EARLY_INDEX 0    // measured round 5: 0.113 ms instead of 0.090 (the extra 32 B per background pixel cost more than the saved round trip)
+#endif
 constexpr int kFwdViews = 16;
 struct FwdViews {
     const float* wi[kFwdViews];
@@ -148,8 +151,18 @@ __global__ __launch_bounds__(256) void gauss_fwd_views_kernel(const float4* __re
         float4 rows[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) rows[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if NF_K10_EARLY_INDEX
+        // Round 5: the index words are requested TOGETHER with the weights (both streams are contiguous per pixel), not behind
+        // the "any weight non-zero" test: the kernel is bound by its chain of dependent round trips (weights -> indices ->
+        // rows), not by bytes; a background pixel now reads 32 bytes it does not use and every foreground pixel is one
+        // memory latency shorter.
+        float4 ia = i4[0], ib = i4[1];
+        asm volatile("" : "+v"(ia.x), "+v"(ia.y), "+v"(ia.z), "+v"(ia.w), "+v"(ib.x), "+v"(ib.y), "+v"(ib.z), "+v"(ib.w));   // (not sunk below the branch)
+        if (any) {
+#else
         if (any) {
             const float4 ia = i4[0], ib = i4[1];
+#endif
             const float fi[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
             const int last = (int)Ns - 1;     // (the launcher checks Ns < 2^31)
 #pragma unroll

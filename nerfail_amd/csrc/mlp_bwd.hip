@@ -31,21 +31,6 @@ __global__ void pack_layer_T_kernel(const float* __restrict__ w, int out_f, int 
 }
 
 // ------------------------------------------------------------------------------------- backward data
-struct BwdArgs {
-    const float* packed;     // forward image (alpha / rgb head weights)
-    const float* packedT;    // transposed image
-    const float* packed2;    // the same two images of a SECOND network of the same architecture: tiles >= split use them
-    const float* packedT2;   // (coarse + fine network of one training step in one launch; RN:394 makes them independent)
-    long split;              // first 32-sample tile of the second network (= number of tiles when there is none)
-    const float* d_raw;      // [M,4]
-    const float* acts;       // saved activations
-    float* dz;               // out: all dZ
-    long M;
-    MlpLayout lay;
-    MlpLayoutT layT;
-    TrainLayout tl;
-};
-
 template <int NT>
 __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_kernel(BwdArgs a) {
     constexpr int OTV = NT / 2;
@@ -148,6 +133,20 @@ static int cu_count() {
 
 using namespace nerfail;
 
+// 0 = automatic (LDS-ring form where it applies), 1 = register-streamed form, 2 = LDS-ring form or NERFAIL_EINVAL
+static int bwd_select_from_env() {
+    const char* e = getenv("NERFAIL_BWD_KERNEL");
+    if (e == nullptr) return 0;
+    return e[0] == 'r' ? 1 : (e[0] == 'l' ? 2 : 0);
+}
+static int g_bwd_select = bwd_select_from_env();
+
+extern "C" int nerfail_mlp_bwd_select(int which) {
+    const int prev = g_bwd_select;
+    if (which >= 0 && which <= 2) g_bwd_select = which;
+    return prev;
+}
+
 extern "C" size_t nerfail_mlp_packed_T_floats(int D, int W, int skip) {
     MlpLayout L;
     if (!make_layout(D, W, skip, L)) return 0;
@@ -217,6 +216,10 @@ extern "C" int nerfail_mlp_bwd_data2(const float* packed0, const float* packedT0
     if (blocks > cu_count()) blocks = cu_count();
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = as_stream(stream);
+    a.blocks0 = 0;
+    // W = 256, even depth <= 8: the LDS-ring form (mlp_lds.hip); g_bwd_select / NERFAIL_BWD_KERNEL=reg forces the register form
+    if (g_bwd_select != 1 && W == 256 && !(D & 1) && D >= 2 && D <= 8) return launch_bwd_data_lds(a, W, cu_count(), s);
+    if (g_bwd_select == 2) { set_error("nerfail_mlp_bwd_data: the LDS-ring kernel does not cover this shape"); return NERFAIL_EINVAL; }
     switch (W) {
         case 256: nerf_mlp_bwd_data_kernel<8><<<grid, block, 0, s>>>(a); break;
         case 128: nerf_mlp_bwd_data_kernel<4><<<grid, block, 0, s>>>(a); break;

@@ -171,21 +171,42 @@ __device__ __forceinline__ void encode_sample(const MlpArgs& a, long s, int h, f
     }
 }
 
-// transposed-weight image for the backward-data pass: [layer 1..D-1, feature, views][quad][in-tile][lane][4]
+// transposed-weight image for the backward-data pass: per layer [quad][in-tile][lane][4] (the piece layout of the forward
+// image). The layers lie in the order the backward pass CONSUMES them - views, feature, pts D-1 .. 1 - so that the image is one
+// contiguous stream for the LDS weight ring (round 5, nerf_mlp_bwd_data_lds_kernel); every layer is a whole number of
+// 4*NT-piece ring groups. Every user addresses a layer through w_off[l].
 struct MlpLayoutT {
     unsigned w_off[NERFAIL_MAX_DEPTH + 2];   // index l = 1..D-1 pts layers, D feature, D+1 views
     unsigned total;
 };
 static inline void make_layout_T(int D, int NT, MlpLayoutT& L) {
     unsigned off = 0;
-    for (int l = 0; l <= D + 1; ++l) {
+    L.w_off[0] = 0;
+    for (int l = D + 1; l >= 1; --l) {
         L.w_off[l] = off;
-        if (l == 0) continue;
         const int quads = (l == D + 1) ? (NT / 2) * 4 : NT * 4;
         off += (unsigned)quads * NT * 256;
     }
     L.total = off;
 }
+
+// arguments of the backward-data kernels (mlp_bwd.hip: register-streamed form; mlp_lds.hip: LDS weight ring)
+struct BwdArgs {
+    const float* packed;     // forward image (alpha / rgb head weights)
+    const float* packedT;    // transposed image
+    const float* packed2;    // the same two images of a SECOND network of the same architecture: tiles >= split use them
+    const float* packedT2;   // (coarse + fine network of one training step in one launch; RN:394 makes them independent)
+    long split;              // first 32-sample tile of the second network (= number of tiles when there is none)
+    const float* d_raw;      // [M,4]
+    const float* acts;       // saved activations
+    float* dz;               // out: all dZ
+    long M;
+    int blocks0;             // LDS-ring form: workgroups [0, blocks0) serve the first network's tiles, the others the second's
+    MlpLayout lay;
+    MlpLayoutT layT;
+    TrainLayout tl;
+};
+int launch_bwd_data_lds(const BwdArgs& a, int W, int cus, hipStream_t s);      // mlp_lds.hip; NERFAIL_EINVAL when the shape is not covered
 
 // ---- device helpers shared by the forward and backward kernels -------------------------------------------
 template <int OT>

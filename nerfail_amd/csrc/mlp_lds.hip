@@ -34,6 +34,12 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 #ifndef NF_LDS_SPREAD
 #define NF_LDS_SPREAD 1     // 1: one piece of side work per MFMA shadow (WRing::step, inference kernels); 0: round-2 form
 #endif
+#ifndef NF_LDS_TRAIN_NEWDMA
+#define NF_LDS_TRAIN_NEWDMA 1 // 1: the training kernel on the buffer-form / per-step refill as well
+#endif
+#ifndef NF_LDS_MID_SPLIT
+#define NF_LDS_MID_SPLIT 0  // 1: the next quad's operand preparation in two halves behind two MFMAs
+#endif
 #ifndef NF_LDS_DMA_BUF
 #define NF_LDS_DMA_BUF 1    // 1: LDS-DMA as buffer_load_dwordx4 ... lds (SGPR base + SGPR piece offset + one 32-bit lane offset)
 #endif                      //    0: global_load_lds_dwordx4 (a 64-bit address pair per lane)
@@ -205,7 +211,12 @@ struct WRing {
                     if (SPREAD ? k == 0 : (SYNC && k < C::GPW)) dma(SPREAD ? J : k);
                     post(k);
                     if (k >= R0 && k < R0 + 4) fr[k - R0] = lds_read4(rl + (rd + (k - R0)) * kPiece);
+#if NF_LDS_MID_SPLIT
+                    if (k == R0 + 4) mid(-2);                             // operands 0, 1 of the next quad
+                    if (k == R0 + 5) mid(-3);                             // operands 2, 3
+#else
                     if (k == R0 + 4) mid(-1);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     ++k;
                 }
@@ -286,7 +297,8 @@ struct WRing {
 //                and a store issued there is old enough at the next group boundary (the boundary's counted vmcnt leaves
 //                only the 8 youngest vector-memory operations in flight; stores count like LDS-DMAs, in order).
 struct NoStore { __device__ __forceinline__ void operator()(int, int, const float (&)[4]) const {} };
-template <int NT, int OT, int NQ, int PAD, int NIN, class Ring, class Hook, class BPrep, class TStore = NoStore>
+// ZERO0: the accumulators are not read - the first MFMA of every out tile takes C = 0 (the backward-data layers: no zero fill).
+template <int NT, int OT, int NQ, int PAD, bool ZERO0 = false, int NIN = 0, class Ring, class Hook, class BPrep, class TStore = NoStore>
 __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook, BPrep bprep, TStore tstore = TStore()) {
     using C = LdsCfg<NT>;
     constexpr int HSP = OT >= 4 ? 4 : OT, SPQ = OT / HSP;
@@ -299,13 +311,24 @@ __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook
         for (int sp = 0; sp < SPQ; ++sp) {
             const int done = (q * SPQ + sp + 1) * HSP;
             auto mf = [&](int t, int e, float a) {
-                acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[q][e], acc[sp * HSP + t], 0, 0, 0);
+                if (ZERO0 && q == 0 && e == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[q][e], zero, 0, 0, 0);
+                } else {
+                    acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[q][e], acc[sp * HSP + t], 0, 0, 0);
+                }
             };
             auto pr = [&]() { if (sp == 0) hook(q); };
             auto mid = [&](int e) {                                  // e < 0: all four operands of the next quad; else operand e only
                 if (sp == SPQ - 1 && q + 1 < NQ) {
-                    if (e < 0) bprep(q + 1, bq[q + 1]);
-                    else {
+                    if (e == -1) bprep(q + 1, bq[q + 1]);
+                    else if (e < -1) {                               // halves: -2 -> operands 0, 1; -3 -> operands 2, 3
+                        float tmp[4];
+                        bprep(q + 1, tmp);
+                        const int e0 = e == -2 ? 0 : 2;
+                        bq[q + 1][e0] = tmp[e0];
+                        bq[q + 1][e0 + 1] = tmp[e0 + 1];
+                    } else {
                         float tmp[4];                                // (the three unused elements are dead code after inlining)
                         bprep(q + 1, tmp);
                         bq[q + 1][e] = tmp[e];
@@ -423,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
     const float* const c_alpha = cst + (L.alpha_off - L.b_off[0]);
     const float* const c_rgb = cst + (L.rgb_off - L.b_off[0]);
 
-    WRing<NT, NF_LDS_SPREAD == 1 && !TRAIN, !TRAIN> st;
+    WRing<NT, NF_LDS_SPREAD == 1 && !TRAIN, !TRAIN || NF_LDS_TRAIN_NEWDMA> st;
     st.gsrc = a.packed + lane * 4; st.ring = ring0; st.rl = ring0 + lane * 4;
     st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, (int)(L.w_total * 4), 0x00020000);   // raw buffer: the weight range
     st.voff = lane * 16;
@@ -583,6 +606,184 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
             reinterpret_cast<float4*>(a.raw)[sout] = make_float4(rgb[0], rgb[1], rgb[2], alpha);
     }
     lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight when the workgroup's LDS is released
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K4b backward-data on the LDS weight ring (round 5): dX = W^T dZ through all layers, the structure of the training forward
+// mirrored (mlp_bwd.hip holds the register-streamed form; both write the same bits). What changed against that form:
+//   * the transposed image (laid out in consumption order: views, feature, pts D-1 .. 1; every layer a whole number of ring
+//     groups) reaches the MFMAs through the workgroup's LDS ring - one copy per CU instead of four L2 streams;
+//   * NO pass between layers. The register form masked a layer's 128 accumulator registers in place, stored them, and zeroed the
+//     next 128: ~400 accumulator moves and 128 exposed stores per layer with the matrix pipe idle. Here dZ_i = d_h_{i+1} *
+//     [h_{i+1} > 0] is formed LAZILY where it is consumed - the B operand of quad q is four accumulator registers ANDed with
+//     their ReLU bits (the lazy ReLU of the forward) - and leaves for HBM from those VGPRs behind MFMAs 4..7 of the quad's
+//     first step (the training forward's activation stores); the output array starts from C = 0 in its first MFMA;
+//   * a workgroup serves ONE network (the ring holds one image): workgroups [0, blocks0) walk the first network's tiles, the
+//     others the second's.
+// Same products, same order of additions per accumulator: the stored dZ are bitwise those of nerf_mlp_bwd_data_kernel.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_lds_kernel(BwdArgs a) {
+    using C = LdsCfg<NT>;
+    constexpr int OTV = NT / 2;
+    constexpr int kHeadFloats = (NT * 32 + 3 * OTV * 32 + 3) / 4 * 4;       // alpha head, rgb head (forward image order)
+    __shared__ __attribute__((aligned(16))) float smem[kHeadFloats + C::RP * kPiece];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const MlpLayout& L = a.lay;
+    const TrainLayout& TL = a.tl;
+    const bool second = (int)blockIdx.x >= a.blocks0;                       // workgroup-uniform
+    const float* __restrict__ P = second ? a.packed2 : a.packed;
+    const float* __restrict__ PT = second ? a.packedT2 : a.packedT;
+    const long ntiles_all = (a.M + 31) / 32;
+    const long t_lo = second ? a.split : 0, t_n = second ? ntiles_all - a.split : a.split;
+    const int nb = second ? (int)gridDim.x - a.blocks0 : a.blocks0, bi = second ? (int)blockIdx.x - a.blocks0 : (int)blockIdx.x;
+    float* const c_alpha = smem;
+    float* const c_rgb = smem + NT * 32;
+    float* const ring0 = smem + kHeadFloats;
+    for (int i = tid; i < NT * 32; i += 256) c_alpha[i] = P[L.alpha_off + i];
+    for (int i = tid; i < 3 * OTV * 32; i += 256) c_rgb[i] = P[L.rgb_off + i];
+    __syncthreads();
+
+    WRing<NT, false, true> st;
+    st.gsrc = PT + lane * 4; st.ring = ring0; st.rl = ring0 + lane * 4;
+    st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)PT, 0, (int)(a.layT.total * 4), 0x00020000);
+    st.voff = lane * 16;
+    st.total = (int)(a.layT.total / kPiece); st.src = 0; st.slot = 0; st.rd = 0; st.wave = wave;
+    st.start();
+
+    f32x16 X[NT], Y[NT];                                                    // two gradient arrays swap roles from layer to layer
+    const int nrounds = (int)((t_n + (long)nb * 4 - 1) / ((long)nb * 4));
+    for (int rnd = 0; rnd < nrounds; ++rnd) {
+        // every wave walks the whole stream every round; one without a tile of its own recomputes the range's last tile and
+        // writes the same bytes again (no branch in the pinned schedule)
+        const long own = ((long)rnd * nb + bi) * 4 + wave;
+        const long tile = t_lo + (own < t_n ? own : t_n - 1);
+        int jj = j, hh = h, l2 = lane;
+        asm volatile("" : "+v"(jj), "+v"(hh), "+v"(l2));                    // lane values recomputed per tile (not hoisted + spilled)
+        const long sraw = tile * 32 + jj;
+        const float* __restrict__ A = a.acts + (size_t)tile * TL.a_slots * 1024;
+        float* __restrict__ Z = a.dz + (size_t)tile * TL.z_slots * 1024;
+        const float* const Amask = A + TL.a_MASK * 1024;
+        const unsigned voff = (unsigned)acc_lane_off(l2) * 4u;
+        float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sraw < a.M) dr = reinterpret_cast<const float4*>(a.d_raw)[sraw];   // padded samples carry zero gradient
+        TileMask<NT> mk = load_mask<NT>(Amask, L.D - 1, l2);                // ReLU bits of h_D: the first pts layer of the chain
+        // ---- ZR: d_raw as a tile (channels 0..3 live in half 0, registers 0..3)
+        {
+            f32x16 zr[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zr[0][r] = 0.f;
+            if (hh == 0) { zr[0][0] = dr.x; zr[0][1] = dr.y; zr[0][2] = dr.z; zr[0][3] = dr.w; }
+            store_tiles<1>(Z + TL.z_ZR * 1024, zr, l2);
+        }
+        // ---- rgb_linear backward: dZ_v = (W_rgb^T d_rgb) * [hv > 0]   (VALU; operands of the views part)
+        f32x16 dzv[OTV];
+        {
+            const TileMask<OTV> mhv = load_mask<OTV>(Amask, L.D, l2);
+#pragma unroll
+            for (int t = 0; t < OTV; ++t) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 w0 = lds_read4(c_rgb + ((0 * OTV + t) * 2 + hh) * 16 + 4 * r4);
+                    const f32x4 w1 = lds_read4(c_rgb + ((1 * OTV + t) * 2 + hh) * 16 + 4 * r4);
+                    const f32x4 w2 = lds_read4(c_rgb + ((2 * OTV + t) * 2 + hh) * 16 + 4 * r4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = w0[e] * dr.x + w1[e] * dr.y + w2[e] * dr.z;
+                        dzv[t][4 * r4 + e] = mask_apply<OTV>(mhv, t, 4 * r4 + e, g);
+                    }
+                }
+            }
+            store_tiles<OTV>(Z + TL.z_ZV * 1024, dzv, l2);
+        }
+        // ---- views_linears[0] backward (feature columns): X = d_feature = Wv[:, :W]^T dZ_v. Meanwhile Y (dead) receives
+        // w_alpha * d_sigma, the alpha head's share of d_h_D, tile by tile.
+        lds_part<NT, NT, OTV * 4, 0, true>(st, X,
+            [&](int q) {
+                if (q < NT) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 w = lds_read4(c_alpha + (q * 2 + hh) * 16 + 4 * r4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Y[q][4 * r4 + e] = w[e] * dr.w;
+                    }
+                }
+            },
+            [&](int q, float (&b)[4]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = dzv[q >> 2][4 * (q & 3) + e];
+            });
+        // ---- feature_linear backward: Y += Wf^T d_feature; dZ_F = d_feature leaves as it is consumed (no activation)
+        {
+            const float* const ZF = Z + TL.z_ZF * 1024;
+            lds_part<NT, NT, 4 * NT, 0>(st, Y, [](int) {},
+                [&](int q, float (&b)[4]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = X[q >> 2][4 * (q & 3) + e];
+                },
+                [&](int q, int e, const float (&b)[4]) { st_acc_reg(ZF + (q >> 2) * 1024, voff, 4 * (q & 3) + e, b[e]); });
+        }
+        // ---- pts_linears[D-1 .. 1]: out = W_i^T (in * [h_{i+1} > 0]); the masked operand is dZ_i and is stored from the VGPRs
+        // it is consumed from. The NEXT layer's bit mask is requested at the head of the layer before.
+        auto layer = [&](f32x16 (&in)[NT], f32x16 (&out)[NT], int i) {
+            const float* const Zi = Z + (TL.z_Z0 + i * NT) * 1024;
+            const TileMask<NT> m = mk;
+            lds_part<NT, NT, 4 * NT, 0, true>(st, out,
+                [&](int q) { if (q == 0) mk = load_mask<NT>(Amask, i - 1, l2); },
+                [&](int q, float (&b)[4]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = mask_apply<NT>(m, q >> 2, 4 * (q & 3) + e, in[q >> 2][4 * (q & 3) + e]);
+                },
+                [&](int q, int e, const float (&b)[4]) { st_acc_reg(Zi + (q >> 2) * 1024, voff, 4 * (q & 3) + e, b[e]); });
+        };
+#pragma unroll 1
+        for (int i = L.D - 1; i >= 2; i -= 2) {                             // D is even (host check): pairs, then layer 1
+            layer(Y, X, i);
+            layer(X, Y, i - 1);
+        }
+        layer(Y, X, 1);
+        // ---- dZ_0 = d_h_1 * [h_1 > 0]: stored only (the chain stops here: no gradient w.r.t. the inputs, RN:394)
+        {
+            const float* const Z0 = Z + TL.z_Z0 * 1024;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = X[t][r];
+                    asm("" : "+v"(v));
+                    st_acc_reg(Z0 + t * 1024, voff, r, mask_apply<NT>(mk, t, r, v));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight when the workgroup's LDS is released
+}
+
+int launch_bwd_data_lds(const BwdArgs& a, int W, int cus, hipStream_t s) {
+    using C = LdsCfg<8>;
+    const long ntiles = (a.M + 31) / 32, t0 = a.split, t1 = ntiles - a.split;
+    if (W != 256 || (a.lay.D & 1) || a.lay.D < 2 || a.lay.D > C::kMaxDepth || (a.layT.total / kPiece) % C::GP != 0 ||
+        a.layT.total / kPiece < (unsigned)C::GP || ntiles >= (1L << 31)) {
+        set_error("nerf_mlp_bwd_data_lds_kernel: shape not covered");
+        return NERFAIL_EINVAL;
+    }
+    // workgroups per network in proportion to its tiles (at least one where there are tiles, whole 4-tile rounds)
+    long blocks = (ntiles + 3) / 4;
+    if (blocks > cus) blocks = cus;
+    long b0 = t1 == 0 ? blocks : (t0 == 0 ? 0 : (blocks * t0 + ntiles / 2) / ntiles);
+    if (t0 > 0 && b0 < 1) b0 = 1;
+    if (t1 > 0 && b0 > blocks - 1) b0 = blocks - 1;
+    if (t0 > 0 && t1 > 0 && blocks < 2) { blocks = 2; b0 = 1; }
+    if (b0 > (t0 + 3) / 4) b0 = (t0 + 3) / 4;                                // never more workgroups than 4-tile rounds
+    long b1 = blocks - b0;
+    if (b1 > (t1 + 3) / 4) b1 = (t1 + 3) / 4;
+    BwdArgs k = a;
+    k.blocks0 = (int)b0;
+    nerf_mlp_bwd_data_lds_kernel<8><<<dim3((unsigned)(b0 + b1)), dim3(256), 0, s>>>(k);
+    NF_LAUNCHED("nerf_mlp_bwd_data_lds_kernel");
+    return NERFAIL_OK;
 }
 
 template <int NT>

@@ -33,6 +33,7 @@ EXPERIMENTS = {
     # round 4, K11: the per-wave LDS slice doubled = half the waves per CU (how much does the segmented reduce depend on occupancy?)
     'seg_lds2': ('gauss_csr.hip', [], ['-DNF_SEG_LDS_MULT=2']),
     # (the round-2/3 ablations of the old entry-strided reduce - seg_noscan / _nogather / _noemit / _u16 / _u4 - went with that kernel)
+    'k10_late_index': ('gauss.hip', [], ['-DNF_K10_EARLY_INDEX=0']),
     'lds_base': ('mlp_lds.hip', [], []),
     'lds_gpm2': ('mlp_lds.hip', [], ['-DNF_LDS_GPM=2']),
     'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, hh, emb, demb);\n',
@@ -74,6 +75,8 @@ EXPERIMENTS = {
     'lds_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27776']),          # the last 64 steps of the last of 48 tiles (8192 x 192 samples)
     'lds_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27340']),       # tile 47, steps 80..143 = pts_linears[2]
     'lds_spread_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27340']),
+    'lds_train_newdma': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_NEWDMA=1']),
+    'lds_midsplit': ('mlp_lds.hip', [], ['-DNF_LDS_MID_SPLIT=1']),
     'lds_spread0': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=0']),
     'lds_spread2': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=2']),
     'lds_spread_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27776']),
