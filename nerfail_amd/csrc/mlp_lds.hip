@@ -34,6 +34,9 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 #ifndef NF_LDS_SPREAD
 #define NF_LDS_SPREAD 1     // 1: one piece of side work per MFMA shadow (WRing::step, inference kernels); 0: round-2 form
 #endif
+#ifndef NF_LDS_BWD_SP1
+#define NF_LDS_BWD_SP1 1      // the backward-data ring kernel on the one-piece-of-side-work-per-shadow step form
+#endif
 #ifndef NF_LDS_TRAIN_NEWDMA
 #define NF_LDS_TRAIN_NEWDMA 1 // 1: the training kernel on the buffer-form / per-step refill as well
 #endif
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_lds_kernel(BwdArgs a
     for (int i = tid; i < 3 * OTV * 32; i += 256) c_rgb[i] = P[L.rgb_off + i];
     __syncthreads();
 
-    WRing<NT, false, true> st;
+    WRing<NT, NF_LDS_BWD_SP1, true> st;
     st.gsrc = PT + lane * 4; st.ring = ring0; st.rl = ring0 + lane * 4;
     st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)PT, 0, (int)(a.layT.total * 4), 0x00020000);
     st.voff = lane * 16;

@@ -258,3 +258,42 @@ def test_joint_backward_equals_separate_launches(golden):
     _train.mlp_backward2(n0, d_raw[:M0], acts[:nA], ga, M0, None, None, 0, accumulate=True)
     for a, b in zip(ga, gs0):
         assert l2_err(N(a), 2.0 * N(b)) < 2e-6
+
+
+@pytest.mark.parametrize('R0,R1', [(64, 0), (20, 37), (3, 1), (128, 384)])
+def test_lds_ring_backward_data_stores_the_same_bits_as_the_register_kernel(R0, R1):
+    """Round 5: nerfail_mlp_bwd_data2 runs nerf_mlp_bwd_data_lds_kernel at W = 256 (the transposed image through the LDS weight
+    ring, dZ formed lazily from the ReLU bits where it is consumed and stored from there, one network per workgroup). Every
+    stored dZ - all layers, both networks of a joint launch, ragged last tiles, fewer tiles than waves - must be BITWISE what the
+    register-streamed nerf_mlp_bwd_data_kernel stores (same products, same order of additions per accumulator)."""
+    from nerfail_amd import _lib, _train
+    lib = _lib.load()
+    _, n0 = hip_nerf(8, 256, 61, requires_grad=True)
+    _, n1 = hip_nerf(8, 256, 62, requires_grad=True)
+    rs = np.random.RandomState(R0 + R1)
+    N0, N1 = 64, 192
+    M0, M1 = R0 * N0, R1 * N1
+    M0 = (M0 + 31) // 32 * 32 if M1 else M0                    # (a joint launch needs whole tiles of the first network)
+    vd = torch.nn.functional.normalize(T(rs.normal(size=(max(R0, R1, 1), 3)).astype(np.float32)), dim=-1)
+    acts = torch.empty((_train.acts_floats(n0, M0) + (_train.acts_floats(n1, M1) if M1 else 0),), device=dev())
+    nA = _train.acts_floats(n0, M0)
+    R0e = M0 // N0
+    _train.mlp_fwd_train(n0, T(rs.normal(size=(R0e, N0, 3)).astype(np.float32)), vd[:R0e].contiguous(), acts=acts[:nA])
+    if M1:
+        _train.mlp_fwd_train(n1, T(rs.normal(size=(R1, N1, 3)).astype(np.float32)), vd[:R1].contiguous(), acts=acts[nA:])
+    d_raw = T((rs.normal(size=(M0 + M1, 4)) * 10.0 ** rs.uniform(-4, 0, (M0 + M1, 1))).astype(np.float32))
+    (p0, pT0), (p1, pT1) = _train.packed_both(n0), _train.packed_both(n1)
+    nz = _train.dz_floats(n0, M0) + (_train.dz_floats(n1, M1) if M1 else 0)
+    out = {}
+    for which in (1, 2):
+        dz = torch.full((nz,), float('nan'), device=dev())
+        prev = lib.nerfail_mlp_bwd_select(which)
+        try:
+            _lib.check(lib.nerfail_mlp_bwd_data2(_lib.dev(p0), _lib.dev(pT0), M0, _lib.dev(p1) if M1 else None, _lib.dev(pT1) if M1 else None,
+                                                 M1, 8, 256, n0._skip(), _lib.dev(d_raw), _lib.dev(acts), _lib.dev(dz), _lib.stream()))
+        finally:
+            lib.nerfail_mlp_bwd_select(prev)
+        torch.cuda.synchronize()
+        out[which] = dz
+    assert not torch.isnan(out[1]).any()
+    assert torch.equal(out[1], out[2])
