@@ -104,7 +104,8 @@ def kernel_source_hash():
 KERNEL_SOURCES = {'nerf_mlp_fwd_lds_kernel': ('mlp_lds.hip', 'mlp_layout.h', 'common.h'),
                   'gauss_': ('gauss.hip', 'gauss_csr.hip', 'common.h'), 'igsm_': ('gauss.hip', 'common.h'),
                   'seg_': ('gauss_csr.hip', 'common.h')}
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_hbm_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_hbm_traffic.json')
+PMC_SQ_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_sq_render.json')
 
 
 def _kernel_key(name):
@@ -113,6 +114,24 @@ def _kernel_key(name):
     if name.startswith('void '):
         name = name[5:]
     return name.replace('nerfail::', '').replace(' ', '')
+
+
+def pmc_mfma_busy(kernel):
+    """Matrix-pipe utilisation of a kernel from the stored SQ counter pass (tools/r05_pmc_sq.sh: SQ_VALU_MFMA_BUSY_CYCLES over the
+    SIMD-cycles of the dispatch, and the clock the chip held) - reported only while the kernel's sources are unchanged."""
+    try:
+        pmc = json.load(open(PMC_SQ_FILE))
+    except (OSError, ValueError):
+        return None
+    now, then = kernel_source_hashes(), pmc.get('csrc_files', {})
+    files = next((v for k, v in KERNEL_SOURCES.items() if k in kernel), tuple(now))
+    if any(now.get(f) != then.get(f) for f in files):
+        return None
+    want = _kernel_key(kernel)
+    for name, v in pmc.get('kernels', {}).items():
+        if _kernel_key(name) == want and 'mfma_busy' in v:
+            return {'mfma_busy': v['mfma_busy'], 'clock_GHz': v.get('clock_GHz'), 'file': 'profiles/' + os.path.basename(PMC_SQ_FILE)}
+    return None
 
 
 def pmc_traffic(kernel_substr, which='avg'):
@@ -1012,6 +1031,8 @@ def child_render(args, emit):
                          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
                          'traffic': traffic, 'traffic_unit': 'HBM+IC bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                          'traffic_source': traffic_source,
+                         'mfma_busy': (pmc_mfma_busy('nerf_mlp_fwd_lds_kernel<8,1,false>') or {}).get('mfma_busy'),
+                         'mfma_busy_source': pmc_mfma_busy('nerf_mlp_fwd_lds_kernel<8,1,false>'),
                          'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
                          'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
             # the other roofline the north star asks for: achieved HBM rate of the compositing scan (K5 + K7)

@@ -422,6 +422,35 @@ __device__ __forceinline__ float lds_head(const f32x16 (&x)[NIN], const float* w
     return s + __shfl_xor(s, 32, 64);
 }
 
+// Three heads over the same input (rgb_linear's three rows): every accumulator register is read ONCE (round 5: three calls of
+// lds_head moved each of the 64 registers to a VGPR three times - an accumulator read goes through the matrix pipe, ~13 cycles).
+// Each sum is the same fma chain in the same order as lds_head's: the bits do not change.
+template <int OT, int NIN>
+__device__ __forceinline__ void lds_head3(const f32x16 (&x)[NIN], const float* w, int stride, int h, float (&out)[3]) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float* p = w + (t * 2 + h) * 16 + 4 * r4;
+            const f32x4 w0 = lds_read4(p), w1 = lds_read4(p + stride), w2 = lds_read4(p + 2 * stride);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = x[t][4 * r4 + e];
+                asm("" : "+v"(v));
+                v = relu_bits(v);
+                s0 = fmaf(w0[e], v, s0);
+                s1 = fmaf(w1[e], v, s1);
+                s2 = fmaf(w2[e], v, s2);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    out[0] = s0 + __shfl_xor(s0, 32, 64);
+    out[1] = s1 + __shfl_xor(s1, 32, 64);
+    out[2] = s2 + __shfl_xor(s2, 32, 64);
+}
+
 // SKIP: where the skip connection's extra part is compiled in: 0 nowhere, 1 first / 2 second layer of a pair.
 // TRAIN: additionally saves what the backward needs (mlp_layout.h: encodings, every layer's post-ReLU tile, the feature
 // tile, ReLU bit masks) - same values, same slots as the register-streamed nerf_mlp_fwd_kernel<NT, true>.
@@ -598,10 +627,10 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
             }
             if (OTV & 1) st_mask16(Amask + L.D * 256, vlane16, OTV, 0u);                 // the dword's unused half, as store_mask writes it
         }
-        float rgb[3];
+        float rgb[3];                                                                     // rgb_linear: W/2 -> 3 (RH:118)
+        lds_head3<OTV>(Q, c_rgb, OTV * 32, h, rgb);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)                                                       // rgb_linear: W/2 -> 3 (RH:118)
-            rgb[c] = lds_head<OTV>(Q, c_rgb + c * OTV * 32, h) + c_rgb[3 * OTV * 32 + c];
+        for (int c = 0; c < 3; ++c) rgb[c] += c_rgb[3 * OTV * 32 + c];
         int je = j;                                  // recomputed: the sample index need not live through the tile
         asm volatile("" : "+v"(je));
         const long sout = (long)tile * 32 + je;
@@ -761,7 +790,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_bwd_data_lds_kernel(BwdArgs a
             }
         }
     }
-    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight when the workgroup's LDS is released
+    lds_wait_vmcnt<0>();       // (the ring's last DMAs have landed before the LDS is released)
 }
 
 int launch_bwd_data_lds(const BwdArgs& a, int W, int cus, hipStream_t s) {

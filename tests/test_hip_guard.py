@@ -13,7 +13,7 @@ BENCH = os.path.join(ROOT, 'bench.py')
 
 
 def test_solver_search_is_opt_in():
-    src = open(BENCH).read()
+    src = open(os.path.join(ROOT, 'bench_sections.py')).read()          # (round 5: the sections live beside the GPU-free parent)
     assert "os.environ.get('NERFAIL_BENCH_TUNE_VICTIM', '0') == '1'" in src        # cudnn.benchmark only on request
     assert src.count('    torch.backends.cudnn.benchmark = True') == 1 and 'if tuned:' in src
 

@@ -81,11 +81,6 @@ EXPERIMENTS = {
     'lds_spread0': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=0']),
     'lds_spread2': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=2']),
     'lds_spread_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27776']),
-    'lds_emajor': ('mlp_lds.hip', [
-        ('        for (int t = 0; t < HSP; ++t) {\n#pragma unroll\n            for (int e = 0; e < 4; ++e) {\n                mf(t, e, cur[t][e]);',
-         '        for (int e = 0; e < 4; ++e) {\n#pragma unroll\n            for (int t = 0; t < HSP; ++t) {\n                mf(t, e, cur[t][e]);'),
-        ('            if (t == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n                prefetch();',
-         '            if (e == 0) {\n                __builtin_amdgcn_sched_barrier(0);\n                prefetch();')], []),
     # clock probes of the register-streamed forward kernel and of the LDS-staged weight-gradient kernel (tools/fwd_clock.py,
     # tools/dw_balance.py read the stamps; outputs destroyed)
     'fwd_clock': ('mlp.hip', [

@@ -27,7 +27,13 @@ def main():
             k = r['Kernel_Name'].split('(')[0]
             if k in per:
                 dur[k].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9)
-    out = {'command': cmd, 'units': 'means per dispatch; SQ_* wave counters in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles summed '
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    try:                                       # ties the measurement to the kernel sources it was taken from (as pmc_summary.py does)
+        import bench_sections as B
+        files = B.kernel_source_hashes()
+    except Exception:
+        files = {}
+    out = {'command': cmd, 'csrc_files': files, 'units': 'means per dispatch; SQ_* wave counters in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles summed '
                                     'over all SIMDs, GRBM_GUI_ACTIVE summed over the 8 XCDs', 'kernels': {}}
     for k, cs in sorted(per.items()):
         m = {c: sum(v) / len(v) for c, v in cs.items()}
