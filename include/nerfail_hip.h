@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NERFAIL_ABI_VERSION 5
+#define NERFAIL_ABI_VERSION 6
 
 #define NERFAIL_OK 0
 #define NERFAIL_EINVAL 1   /* bad argument (null pointer, size, unsupported shape) */

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: libnerfail_hip.so binds to 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFAIL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerfail_hip.so')   # override: A/B builds (tools/ablate.py)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_DEPTH = 16
 DW_BF16X3, DW_ACCUMULATE = 1, 2          # flags of nerfail_mlp_bwd_weights
 RAY_FLOATS = 11
