@@ -204,15 +204,20 @@ def test_render_rays_cfg2(golden):
                        white_bkgd=True)
     for k in keys:
         assert rel_err(N(r[k]), g['cfg2_det_' + k]) < 1e-4, k
-    for k in ('rgb_map', 'acc_map', 'pts_max'):      # the unfloored max |a-b|/|b| next to it
-        print('cfg2 %-8s rel_err %.2e  plain max relative %.2e' % (k, rel_err(N(r[k]), g['cfg2_det_' + k]),
-                                                                  plain_rel_err(N(r[k]), g['cfg2_det_' + k])))
-        assert plain_rel_err(N(r[k]), g['cfg2_det_' + k]) < 1e-3, k
+    # The LITERAL reading of "1e-4 rel" (VERDICT r4): max |a-b| / |b| over every non-zero reference entry, no floor - on EVERY
+    # composited output, both passes, deterministic and perturbed (round 4 asserted it at 1e-3 on three keys only).
+    def literal(rr, tag):
+        for k in keys:
+            e = plain_rel_err(N(rr[k]), g['cfg2_%s_%s' % (tag, k)])
+            print('cfg2 %-4s %-8s rel_err %.2e  literal max |a-b|/|b| %.2e' % (tag, k, rel_err(N(rr[k]), g['cfg2_%s_%s' % (tag, k)]), e))
+            assert e < 1e-4, (tag, k, e)
+    literal(r, 'det')
     assert rel_err(N(r['raw']), g['cfg2_det_raw']) < 1e-2
     r = NC.render_rays(T(g['cfg2_rays']), coarse, None, 64, retraw=True, N_importance=128, network_fine=fine,
                        white_bkgd=True, perturb=1., t_rand=T(g['cfg2_t_rand']), u=T(g['cfg2_u']))
     for k in keys:
         assert rel_err(N(r[k]), g['cfg2_pert_' + k]) < 1e-4, k
+    literal(r, 'pert')
     # the run_nerf flavour has no pts_max and the same maps
     r2 = RN.render_rays(T(g['cfg2_rays']), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True)
     assert 'pts_max' not in r2
