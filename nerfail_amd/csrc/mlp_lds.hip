@@ -34,6 +34,9 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 #ifndef NF_LDS_SPREAD
 #define NF_LDS_SPREAD 1     // 1: one piece of side work per MFMA shadow (WRing::step, inference kernels); 0: round-2 form
 #endif
+#ifndef NF_LDS_RING_FIRST
+#define NF_LDS_RING_FIRST 1
+#endif
 #ifndef NF_LDS_BWD_SP1
 #define NF_LDS_BWD_SP1 1      // the backward-data ring kernel on the one-piece-of-side-work-per-shadow step form
 #endif
@@ -466,9 +469,18 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const MlpLayout& L = a.lay;
+#if NF_LDS_RING_FIRST
+    // the ring at offset 0: a step's four fragment reads are then ONE address (lane * 16 + ring piece * 1024) + immediates
+    // 0 .. 3072 - with the ring behind the constants its last two reads fell outside the 16-bit offset and every step paid a
+    // second vector add (580 per tile; vector instructions are never hidden beside the f32 MFMA)
+    float* const ring0 = smem;
+    float* const cst = smem + C::RP * kPiece;
+    float* const park = cst + C::kConstMax + wave * (64 * 4 * C::kParkQuads) + lane * 4;
+#else
     float* const cst = smem;
     float* const park = smem + C::kConstMax + wave * (64 * 4 * C::kParkQuads) + lane * 4;
     float* const ring0 = smem + C::kConstMax + C::kParkFloats;
+#endif
     {   // constant area: biases (one piece per layer), alpha head, rgb head
         const int n = (int)(L.total - L.b_off[0]);
         const float* __restrict__ g = a.packed + L.b_off[0];
@@ -495,6 +507,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
         const f32x4 v0 = lds_read4(p), v1 = lds_read4(p + 4), v2 = lds_read4(p + 8), v3 = lds_read4(p + 12);
         dst[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
                           v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+        // pinned into accumulator registers HERE (round 5; the LDS read then targets them directly): left alone hipcc keeps bias
+        // tiles in VGPRs whenever it has some to spare and moves them over with v_accvgpr_write in front of a layer's first
+        // MFMAs (280-320 such moves in the kernel's code, 0 with the pin). Vector instructions are never free beside the
+        // f32 MFMA (see the note on the encoding-overlap experiment in DESIGN.md): every one removed is time gained.
+        asm volatile("" : "+a"(dst[t]));
     };
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias_tile(P, 0, t);                                     // later rounds: written by the views layer

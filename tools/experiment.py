@@ -75,6 +75,7 @@ EXPERIMENTS = {
     'lds_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27776']),          # the last 64 steps of the last of 48 tiles (8192 x 192 samples)
     'lds_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27340']),       # tile 47, steps 80..143 = pts_linears[2]
     'lds_spread_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27340']),
+    'lds_ring_last': ('mlp_lds.hip', [], ['-DNF_LDS_RING_FIRST=0']),
     'bwd_sp0': ('mlp_lds.hip', [], ['-DNF_LDS_BWD_SP1=0']),
     'lds_train_newdma': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_NEWDMA=1']),
     'lds_midsplit': ('mlp_lds.hip', [], ['-DNF_LDS_MID_SPLIT=1']),
