@@ -28,3 +28,4 @@ bash tools/r05_pmc_sq.sh render || exit 1
 cp gpurun_out/r05/pmc_sq/pmc_sq_render.json $O/pmc_sq_render.json
 find gpurun_out/r05/pmc_sq -name "*counter_collection.csv" -delete; find gpurun_out/r05/pmc_sq -name "*kernel_trace.csv" -delete
 echo "profiles done"
+timeout -k 10 300 python3 __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc $?"; tail -2 $O/smoke.log
