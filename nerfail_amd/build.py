@@ -24,6 +24,12 @@ CFLAGS = ['-O3', '--offload-arch=' + ARCH, '-fPIC', '-std=c++17', '-ffp-contract
           '-Wno-unused-function', '-I', INCLUDE]
 
 
+# per-file flags. mlp_lds.hip: its fully unrolled layer loops (32 quads x 32 pinned MFMAs, some as inline asm) exceed the
+# size up to which hipcc honours '#pragma unroll' (16 384); not unrolled, the accumulator arrays would be indexed at run time
+# and live in scratch.
+FILE_FLAGS = {'mlp_lds.hip': ['-mllvm', '-pragma-unroll-threshold=65536']}
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
 
@@ -46,7 +52,7 @@ def build(force=False, verbose=False, extra_flags=()):
         o = os.path.join(OBJDIR, src[:-4] + '.o')
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + CFLAGS + list(extra_flags) + ['-c', s, '-o', o])
+            jobs.append([HIPCC] + CFLAGS + FILE_FLAGS.get(src, []) + list(extra_flags) + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

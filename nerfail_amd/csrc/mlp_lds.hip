@@ -34,6 +34,9 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 #ifndef NF_LDS_SPREAD
 #define NF_LDS_SPREAD 1     // 1: one piece of side work per MFMA shadow (WRing::step, inference kernels); 0: round-2 form
 #endif
+#ifndef NF_LDS_VGPR_P
+#define NF_LDS_VGPR_P 1       // activation array P in arch VGPRs (VGPR-form MFMAs by inline asm; inference, W = 256); 0: both in AGPRs
+#endif
 #ifndef NF_LDS_RING_FIRST
 #define NF_LDS_RING_FIRST 1
 #endif
@@ -304,7 +307,15 @@ struct WRing {
 //                only the 8 youngest vector-memory operations in flight; stores count like LDS-DMAs, in order).
 struct NoStore { __device__ __forceinline__ void operator()(int, int, const float (&)[4]) const {} };
 // ZERO0: the accumulators are not read - the first MFMA of every out tile takes C = 0 (the backward-data layers: no zero fill).
-template <int NT, int OT, int NQ, int PAD, bool ZERO0 = false, int NIN = 0, class Ring, class Hook, class BPrep, class TStore = NoStore>
+// VG (round 5): the output array lives in arch VGPRs - its MFMAs are issued in the VGPR form, so that the NEXT layer reads its B
+// operands without v_accvgpr_read (an accumulator read costs ~9-13 cycles that nothing hides). hipcc selects ONE form per
+// function, hence inline asm. What the compiler then no longer knows is that the statement is an MFMA; the hazards it would
+// have covered do not arise in this use: the accumulate chain reads SrcC = its own vDst back to back (forwarded by the
+// hardware, as in every VGPR-form GEMM), A / B operands come from ds_read (waited for as asm inputs) and v_max (no VALU ->
+// XDL SrcA/B hazard on gfx940+), and a VALU / LDS access to an MFMA result follows its last MFMA by at least a whole step
+// (the 19 wait states a 16-pass XDL write needs are 76 cycles). Round 2's attempt put two wait states in front of every such
+// MFMA and lost what the form gains; test_lds_streaming_kernel_equals_register_streamed_kernel holds the bits.
+template <int NT, int OT, int NQ, int PAD, bool ZERO0 = false, bool VG = false, int NIN = 0, class Ring, class Hook, class BPrep, class TStore = NoStore>
 __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook, BPrep bprep, TStore tstore = TStore()) {
     using C = LdsCfg<NT>;
     constexpr int HSP = OT >= 4 ? 4 : OT, SPQ = OT / HSP;
@@ -320,6 +331,8 @@ __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook
                 if (ZERO0 && q == 0 && e == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[q][e], zero, 0, 0, 0);
+                } else if constexpr (VG) {
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[sp * HSP + t]) : "v"(a), "v"(bq[q][e]));
                 } else {
                     acc[sp * HSP + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[q][e], acc[sp * HSP + t], 0, 0, 0);
                 }
@@ -502,7 +515,8 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
     // consumed its quads 4k..4k+3, so the 4 LDS reads + 16 accumulator writes of a bias tile hide between its MFMAs
     // instead of standing in front of the next layer (bias loads were 1 % of the register-streamed kernel).
     f32x16 P[NT], Q[NT];
-    auto bias_tile = [&](f32x16 (&dst)[NT], int l, int t) {                              // dst[t] = bias of layer l, tile t
+    constexpr bool VGP = NF_LDS_VGPR_P && !TRAIN && NT == 8;                             // array P in arch VGPRs (experiment)
+    auto bias_tile = [&](f32x16 (&dst)[NT], int l, int t, const bool in_vgpr = false) {  // dst[t] = bias of layer l, tile t
         const float* p = cst + l * kPiece + (t * 2 + h) * 16;
         const f32x4 v0 = lds_read4(p), v1 = lds_read4(p + 4), v2 = lds_read4(p + 8), v3 = lds_read4(p + 12);
         dst[t] = (f32x16){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
@@ -511,10 +525,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
         // tiles in VGPRs whenever it has some to spare and moves them over with v_accvgpr_write in front of a layer's first
         // MFMAs (280-320 such moves in the kernel's code, 0 with the pin). Vector instructions are never free beside the
         // f32 MFMA (see the note on the encoding-overlap experiment in DESIGN.md): every one removed is time gained.
-        asm volatile("" : "+a"(dst[t]));
+        if (VGP && in_vgpr) asm volatile("" : "+v"(dst[t]));
+        else asm volatile("" : "+a"(dst[t]));
     };
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bias_tile(P, 0, t);                                     // later rounds: written by the views layer
+    for (int t = 0; t < NT; ++t) bias_tile(P, 0, t, true);                               // later rounds: written by the views layer
 
     // 32-bit tile counters (the launcher checks M < 2^36): a 64-bit "tile < ntiles" has no scalar compare, so ntiles
     // was copied into a VGPR pair that then lived - in scratch - through the whole kernel
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
             for (int e = 0; e < 4; ++e) b[e] = v[e];
         };
         // layer 0: 63 -> W into P (its bias is already there); Q (dead) receives the bias of layer 1 meanwhile
-        lds_part<NT, NT, kEmbQuads, 0>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); },
+        lds_part<NT, NT, kEmbQuads, 0, false, VGP>(st, P, [&](int q) { if (q < NT) bias_tile(Q, 1, q); },
             [&](int q, float (&b)[4]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b[e] = emb[4 * q + e];
@@ -575,10 +590,11 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
         // layer l+1 tile by tile as its tiles die (for l == D that is the views layer: its W/2 channels use the first
         // tiles, the others get unused padding of the piece).
         float alpha = 0.f;
-        auto layer = [&](f32x16 (&in)[NT], f32x16 (&out)[NT], int l, bool may_skip, bool may_be_last) {
+        auto layer = [&](f32x16 (&in)[NT], f32x16 (&out)[NT], int l, bool may_skip, bool may_be_last, auto out_is_p) {
+            constexpr bool OVG = VGP && decltype(out_is_p)::value;                        // out == P: VGPR-form MFMAs; else in == P
             if (may_be_last && l == L.D) alpha = lds_head<NT>(in, c_alpha, h) + c_alpha[NT * 32];   // alpha_linear on relu(h) (RH:110)
             if (may_skip && l == L.skip + 1)                                              // h = cat([input_pts, h]) (RH:106-107)
-                lds_part<NT, NT, kEmbQuads, 0>(st, out, [](int) {}, b_park);
+                lds_part<NT, NT, kEmbQuads, 0, false, OVG>(st, out, [](int) {}, b_park);
             unsigned mk16 = 0u;                                                           // ReLU bits of the tile being consumed
             const float* const Hl = TRAIN ? A + (3 + (l - 1) * NT) * 1024 : nullptr;      // H_l = relu(in): layer l's input
             const float* const Ml = TRAIN ? Amask + (l - 1) * 256 : nullptr;              // its bit-mask entry
@@ -586,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);
             };
-            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); };
+            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1, !decltype(out_is_p)::value); };
             if constexpr (TRAIN) {
                 lds_part<NT, NT, 4 * NT, 0>(st, out, hk, bp, [&](int q, int e, const float (&b)[4]) {
                     const int r = 4 * (q & 3) + e;
@@ -598,19 +614,19 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
                     }
                 });
             } else {
-                lds_part<NT, NT, 4 * NT, 0>(st, out, hk, bp);
+                lds_part<NT, NT, 4 * NT, 0, false, OVG>(st, out, hk, bp);
             }
-            bias_tile(in, l + 1, NT - 1);
+            bias_tile(in, l + 1, NT - 1, !decltype(out_is_p)::value);
         };
 #pragma unroll 1
         for (int l = 1; l < L.D; l += 2) {                                                // D is even (host check): whole pairs
-            layer(P, Q, l, SKIP == 1, false);
-            layer(Q, P, l + 1, SKIP == 2, true);
+            layer(P, Q, l, SKIP == 1, false, std::false_type{});
+            layer(Q, P, l + 1, SKIP == 2, true, std::true_type{});
         }
         // views_linears[0]: cat([feature, embedded dirs]) -> W/2 into Q's first tiles (RH:112-116; its ReLU is applied by
         // the rgb head); P, its input, receives the bias of the NEXT tile's layer 0 as it dies
         {
-            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(P, 0, (q >> 2) - 1); };
+            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(P, 0, (q >> 2) - 1, true); };
             auto bp = [&](int q, float (&b)[4]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b[e] = P[q >> 2][4 * (q & 3) + e];
@@ -624,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
                 lds_part<NT, OTV, 4 * NT, 0>(st, Q, hk, bp);
             }
         }
-        bias_tile(P, 0, NT - 1);
+        bias_tile(P, 0, NT - 1, true);
         lds_part<NT, OTV, kDirQuads, C::kStreamPad>(st, Q, [](int) {}, [&](int q, float (&b)[4]) { b_park(kEmbQuads + q, b); });
         if constexpr (TRAIN) {                                                            // HV = relu(views output) + its bit mask
             const float* const Vl = A + (3 + (L.D + 1) * NT) * 1024;

@@ -75,6 +75,7 @@ EXPERIMENTS = {
     'lds_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27776']),          # the last 64 steps of the last of 48 tiles (8192 x 192 samples)
     'lds_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_ST_LO=27340']),       # tile 47, steps 80..143 = pts_linears[2]
     'lds_spread_steps_l2': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27340']),
+    'lds_agpr_p': ('mlp_lds.hip', [], ['-DNF_LDS_VGPR_P=0']),
     'lds_ring_last': ('mlp_lds.hip', [], ['-DNF_LDS_RING_FIRST=0']),
     'bwd_sp0': ('mlp_lds.hip', [], ['-DNF_LDS_BWD_SP1=0']),
     'lds_train_newdma': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_NEWDMA=1']),
@@ -179,7 +180,7 @@ def main():
                     t = open(os.path.join(tmp, f)).read()
                     open(os.path.join(tmp, f), 'w').write(t.replace('"../../include/', '"' + B.INCLUDE + '/'))
             o = os.path.join(B.OBJDIR, 'exp_%s.o' % name)
-            subprocess.check_call([B.HIPCC] + B.CFLAGS + flags + ['-c', os.path.join(tmp, src), '-o', o])
+            subprocess.check_call([B.HIPCC] + B.CFLAGS + B.FILE_FLAGS.get(src, []) + flags + ['-c', os.path.join(tmp, src), '-o', o])
         finally:
             shutil.rmtree(tmp)
         objs = [os.path.join(B.OBJDIR, f[:-4] + '.o') for f in B._sources() if f != src] + [o]
