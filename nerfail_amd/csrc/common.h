@@ -129,6 +129,21 @@ struct SinCosBands {
         sn = (k & 2) ? -ss : ss;
         cs = ((k + 1) & 2) ? -cc : cc;
     }
+    // h ? cos : sin of band f - the ONE value a lane of the MLP kernels needs (lane half 0 feeds the sine channel of a k-step,
+    // half 1 the cosine channel). cos t = sin(t + pi/2): the quadrant is advanced by h and a single select + sign flip remain
+    // (7 vector instructions instead of 14 behind the two polynomials; round 5: vector instructions are never hidden beside
+    // the f32 MFMA). The same polynomial values, the same sign: bit for bit band()'s h ? cs : sn.
+    __device__ __forceinline__ float band_sel(int f, int h) const {
+        const double u = u0 * (double)(1 << f);
+        const double q = __builtin_rint(u);
+        const float phi = (float)(u - q) * 1.57079632679489661923f;
+        const float z = phi * phi;
+        const float s = phi + phi * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+        const float c = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+        const int k = (int)q + h;
+        const float v = (k & 1) ? c : s;
+        return __uint_as_float(__float_as_uint(v) ^ ((unsigned)(k & 2) << 30));
+    }
 };
 
 // pts = o + d*z with the reference's rounding (multiply, then add; no FMA): RN:381

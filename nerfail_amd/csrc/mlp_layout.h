@@ -135,11 +135,7 @@ __device__ __forceinline__ void encode_sample(const MlpArgs& a, long s, int h, f
         for (int d = 0; d < 3; ++d) {
             const SinCosBands sc(px[d]);
 #pragma unroll
-            for (int f = 0; f < 10; ++f) {
-                float sn, cs;
-                sc.band(f, sn, cs);
-                emb[3 * f + d] = h ? cs : sn;
-            }
+            for (int f = 0; f < 10; ++f) emb[3 * f + d] = sc.band_sel(f, h);
         }
         emb[30] = h ? px[1] : px[0];
         emb[31] = h ? 0.f : px[2];
@@ -147,11 +143,7 @@ __device__ __forceinline__ void encode_sample(const MlpArgs& a, long s, int h, f
         for (int d = 0; d < 3; ++d) {
             const SinCosBands sc(vx[d]);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                float sn, cs;
-                sc.band(f, sn, cs);
-                demb[3 * f + d] = h ? cs : sn;
-            }
+            for (int f = 0; f < 4; ++f) demb[3 * f + d] = sc.band_sel(f, h);
         }
         demb[12] = h ? vx[1] : vx[0];
         demb[13] = h ? 0.f : vx[2];
