@@ -394,6 +394,9 @@ struct DwArgs {
     DwGroup grp[kDwMaxGroups];
 };
 
+#ifndef NF_DW_DMA_BUF
+#define NF_DW_DMA_BUF 0    // measured round 5: the buffer form removes 155 SGPR-spill lane moves and 150 64-bit address adds from the code and is SLOWER here (2.75 vs 2.55 ms; the forward kernel gains from it) - left off
+#endif
 template <int N> __device__ __forceinline__ void dw_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool BF16, int MA, int NB, int LA, int LB>
@@ -439,6 +442,31 @@ __device__ __forceinline__ void dw_group_run(const DwArgs& a, const DwGroup& g, 
     const char* zc = reinterpret_cast<const char*>(a.dz) + ((long)(g.t0 + t_begin) * a.z_slots + g.dz_slot0) * 4096;
     const char* xc = reinterpret_cast<const char*>(a.acts) + ((long)(g.t0 + t_begin) * a.a_slots + g.x_slot0) * 4096;
     int si = 0;
+#if NF_DW_DMA_BUF
+    // Round 5: the LDS-DMA in the buffer form (SGPR resource + SGPR stage offset + the lane's 32-bit piece offset) instead of
+    // global_load_lds with a 64-bit address pair per lane: no 64-bit vector add per piece and a cheaper issue (the forward
+    // kernel's measurement: a DMA of the global form outlasts the 64 cycles of the MFMA it stands behind). The resources start at
+    // this segment's first stage, so the stage offsets stay far below 4 GB whatever the size of the buffers.
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)zc, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xc, 0, 0x7fffffff, 0x00020000);
+    unsigned zo = 0u, xo = 0u;
+    auto dma = [&](int i, int rs) {                                     // piece i of the stage at the cursor -> ring slot rs
+        lds_void_t* dst = (lds_void_t*)(smem + rs * kDwStageFloats + (wave + 4 * i) * 256);
+        // (selected, not branched: isz is wave-uniform - five s_cselect; a branch would cut the pinned schedule)
+        // (pieces wave, wave + 4, ...: with 2 LA a multiple of 4 "piece i is a dZ piece" does not depend on the wave - a
+        // compile-time choice between the two resources; left to a run-time select hipcc kept one descriptor per piece in
+        // SGPRs and spilled them to VGPR lanes)
+        const bool zi = ((2 * LA) % 4 == 0) ? (i < LA / 2) : isz[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(zi ? rz : rx, dst, 16, (int)voff[i], (int)(zi ? zo : xo), 0, 0);
+    };
+    auto advance = [&]() {                                              // branch-free: a branch here would cut the pinned schedule
+        const unsigned go = 0u - (unsigned)(si < S - 1);                // all ones while there is a next stage
+        const bool odd = si & 1;
+        zo += (odd ? (unsigned)ztile - 2048u : 2048u) & go;
+        xo += (odd ? (unsigned)xtile - 2048u : 2048u) & go;
+        si += (int)(go & 1u);
+    };
+#else
     auto dma = [&](int i, int rs) {                                     // piece i of the stage at the cursor -> ring slot rs
         const char* base = isz[i] ? zc : xc;
         __builtin_amdgcn_global_load_lds((glb_void_t*)(base + voff[i]),
@@ -451,6 +479,7 @@ __device__ __forceinline__ void dw_group_run(const DwArgs& a, const DwGroup& g, 
         xc += (odd ? xtile - 2048 : 2048L) & go;
         si -= (int)go;
     };
+#endif
     // operands of two consecutive steps (ping-pong): R[p][t][hf], t < MA: A tiles, then NB B tiles
     f32x4 R[2][NOP][2];
     auto fetch_one = [&](int p, int idx, const char* sbase) {           // LDS -> registers: one ds_read_b128

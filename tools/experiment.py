@@ -111,6 +111,7 @@ EXPERIMENTS = {
     # pricing of the weight-gradient step loop (mlp_dw.hip): no LDS-DMA / no per-step barrier / no LDS operand reads / no row sums
     'dw_nodma': ('mlp_dw.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + voff[i]),\n                                         (lds_void_t*)(smem + rs * kDwStageFloats + (wave + 4 * i) * 256), 16, 0, 0);\n',
                                  '        asm volatile("" :: "v"(base + voff[i]), "s"(rs));\n')], []),
+    'dw_dma_buf': ('mlp_dw.hip', [], ['-DNF_DW_DMA_BUF=1']),
     'dw_nobarrier': ('mlp_dw.hip', [('                dw_wait_vmcnt<(NS - 3) * G>();                          // this wave\'s pieces of stage s+1 have landed\n                __builtin_amdgcn_s_barrier();',
                                      '                dw_wait_vmcnt<(NS - 3) * G>();                          // this wave\'s pieces of stage s+1 have landed\n')], []),
     'dw_nofetch': ('mlp_dw.hip', [('        R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n', '        if (off == -12345) R[p][t][hf] = *reinterpret_cast<const f32x4*>(sbase + off);\n')], []),
