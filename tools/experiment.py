@@ -65,8 +65,8 @@ EXPERIMENTS = {
          '            o_[0] = (unsigned)(c1_ - c0_); o_[1] = (unsigned)(c2_ - c1_); o_[2] = (unsigned)(c3_ - c2_); o_[3] = (unsigned)(c4_ - c3_);\n'
          '            o_[4] = __float_as_uint(rgb[0] + rgb[1] + rgb[2] + alpha); o_[5] = (unsigned)wall_clock64();\n'
          '        }\n')], []),
-    'lds_nobias': ('mlp_lds.hip', [('            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1); };\n', '            auto hk = [&](int q) {};\n'),
-                                   ('            bias_tile(in, l + 1, NT - 1);\n', '')], []),
+    'lds_nobias': ('mlp_lds.hip', [('            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1, !decltype(out_is_p)::value); };\n', '            auto hk = [&](int q) {};\n'),
+                                   ('            bias_tile(in, l + 1, NT - 1, !decltype(out_is_p)::value);\n', '')], []),
     'lds_norelu': ('mlp_lds.hip', [('b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);', 'b[e] = in[q >> 2][4 * (q & 3) + e];')], []),
     'lds_noread': ('mlp_lds.hip', [('        for (int t = 0; t < C::HS; ++t) fr[t] = lds_read4(rl + (rd + t) * kPiece);\n    }\n    __device__ __forceinline__ void start()',
                                     '        for (int t = 0; t < C::HS; ++t) asm volatile("" : "+v"(fr[t]));\n    }\n    __device__ __forceinline__ void start()')], []),
