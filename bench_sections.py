@@ -933,6 +933,8 @@ def child_render(args, emit):
                 dist.all_reduce(ones)                                # creates the communicator now (banner -> stderr)
                 torch.cuda.synchronize()
                 rccl_ranks = int(ones.item())                        # ranks that really took part in an RCCL collective
+                # asserted BEFORE the timed region: a line that says n_gpus N was measured on N RCCL ranks
+                assert rccl_ranks == world, 'RCCL all-reduce of ones returned %d on a %d-rank group' % (rccl_ranks, world)
             else:
                 dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=to)
     assert world == args.gpus, '--gpus %d but WORLD_SIZE %d (bench.py spawns the ranks itself when no launcher did)' % (args.gpus, world)
