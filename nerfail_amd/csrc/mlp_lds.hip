@@ -386,7 +386,8 @@ __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook
     }
     // VG: nothing may read an MFMA result in VGPRs for 19 wait states after a 16-pass MFMA was issued, and hipcc - which does not
     // know the asm statements are MFMAs - is free to put a register copy of the array right behind the part's last one (the
-    // backward-data kernel with its X array in VGPRs, tried in round 5, produced wrong bits that way). 20 wait states close it.
+    // backward-data kernel with its X array in VGPRs, tried in round 5, produced wrong bits; the cause was not isolated, such
+    // a copy is the suspected path). 20 wait states close it.
     if constexpr (VG) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
     for (int p = 0; p < PAD / HSP; ++p) {
