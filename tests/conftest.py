@@ -126,13 +126,30 @@ def l2_err(a, b):
 def trained_pair_inputs(g):
     """Fixture g21 (a pair TRAINED and rendered by the reference, tests/golden/make_golden.py g21): state dicts, the 4 096 rays
     and the perturbed pass's draws - regenerated from the stored seed exactly as the generator drew them."""
-    sc = {k[len('coarse_'):]: g[k] for k in g if k.startswith('coarse_')}
-    sf = {k[len('fine_'):]: g[k] for k in g if k.startswith('fine_')}
+    w = g
+    if 'weights_file' in g:          # g22: the D=8 W=256 pair is input data of its own (tests/golden/g22_weights.npz)
+        w = dict(np.load(os.path.join(GOLDEN, str(g['weights_file']))))
+    sc = {k[len('coarse_'):]: w[k] for k in w if k.startswith('coarse_')}
+    sf = {k[len('fine_'):]: w[k] for k in w if k.startswith('fine_')}
     rays = g['rays']
     rs = np.random.RandomState(int(g['draw_seed']))
     t_rand = rs.uniform(size=(rays.shape[0], 64)).astype(np.float32)
     u = rs.uniform(size=(rays.shape[0], 128)).astype(np.float32)
     return sc, sf, rays, t_rand, u
+
+
+def trained_subset(g, n):
+    """The first n rays of a trained-pair fixture (g21 / g22), with the yardstick - how many rays the reference's own fp32
+    and fp64 runs disagree on beyond 1e-4 - RECOUNTED on those n rays from the stored fp64 outputs (the stored
+    scalar counts over all 4 096 rays; holding a 1 024-ray subset to it was about 4x too loose). `ref_max_abs`, the size
+    of the reference pair's worst ray, stays the whole set's: it says what a flipped bin looks like in this scene."""
+    R = g['rays'].shape[0]
+    sub = {k: (v[:n] if getattr(v, 'shape', ()) and v.shape[:1] == (R,) else v) for k, v in g.items()}
+    for tag in ('det', 'pert'):
+        d = np.abs(sub[tag + '_rgb_map'].astype(np.float64) - sub[tag + '_f64_rgb_map']).max(1)
+        da = np.abs(sub[tag + '_acc_map'].astype(np.float64) - sub[tag + '_f64_acc_map'])
+        sub[tag + '_ref_rays_over_1e-4'] = int(((d > 1e-4) | (da > 1e-4)).sum())
+    return sub
 
 
 def check_against_trained_reference(g, tag, got, who):

@@ -16,7 +16,9 @@ def attack_inputs():
     ori = synth.disc_alpha_image(B, H, W, seed=8)
     dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
     idx = rs.randint(0, P * H * W, (B, H, W, 8)).astype(np.float32)
-    cls_w = (rs.normal(size=(8, 3 * 4 * 4)) * 0.05).astype(np.float32)
+    # images are 0..255: the logits must stay O(1). (Until round 6 the scale was 0.05: logit 125 on the labelled class, a
+    # saturated softmax, CE = 0 and a perturbation gradient of 2e-39 - every gradient comparison built on it was vacuous.)
+    cls_w = (rs.normal(size=(8, 3 * 4 * 4)) * 1e-3).astype(np.float32)
     return dict(s0=s0, ori=ori, dist_and_index=np.stack([dist, idx], 1), cls_w=cls_w)
 
 

@@ -499,3 +499,45 @@ def test_render_rays_on_a_pair_trained_by_the_reference(golden):
     d = np.abs(N(r['pts_max']) - g['det_pts_max']).max(1)[same]
     print('argmax point: %d of %d unflipped rays differ by more than 1e-4 (worst %.3f)' % (int((d > 1e-4).sum()), d.size, d.max()))
     assert (d > 1e-4).mean() < 0.01 and d.max() < 0.1
+
+
+def test_render_rays_headline_shape_on_trained_weights(golden):
+    """the same judgement at the HEADLINE shape. g22 = a D=8 W=256 coarse + fine pair (RN:435-441, the
+    shipped configs) trained for 2 000 steps on the analytic sphere (tests/golden/g22_weights.npz: input data), rendered by the
+    REFERENCE on 4 096 rays, deterministic and perturbed, in fp32 and in fp64. The HIP path (the LDS-ring f32 MFMA kernel the
+    headline number is measured on) is held to the reference's fp32 outputs: the coarse pass on every ray, the whole path up
+    to the number of rays the reference's own two precisions disagree on (RH:200-243 flips, conftest)."""
+    from nerfail_amd import nerf_to_coord as NC
+    from nerfail_amd.run_nerf_helpers import NeRF
+    g = golden('g22_trained_pair_d8')
+    sc, sf, rays, t_rand, u = trained_pair_inputs(g)
+
+    def net(sd):
+        m = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.requires_grad_(False).to(dev())
+    coarse, fine = net(sc), net(sf)
+    with torch.no_grad():
+        r = NC.render_rays(T(rays), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True)
+        rp = NC.render_rays(T(rays), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.,
+                            t_rand=T(t_rand), u=T(u))
+    check_against_trained_reference(g, 'det', {k: N(v) for k, v in r.items()}, 'HIP D8W256')
+    check_against_trained_reference(g, 'pert', {k: N(v) for k, v in rp.items()}, 'HIP D8W256')
+    same = np.abs(N(r['rgb_map']) - g['det_rgb_map']).max(1) < 1e-5
+    d = np.abs(N(r['pts_max']) - g['det_pts_max']).max(1)[same]
+    print('argmax point: %d of %d unflipped rays differ by more than 1e-4 (worst %.3f)' % (int((d > 1e-4).sum()), d.size, d.max()))
+    assert (d > 1e-4).mean() < 0.01 and d.max() < 0.1
+    # both forward kernels (LDS ring = default, register-streamed) give the same bits on trained weights too
+    from nerfail_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.nerfail_mlp_fwd_select(1)
+        with torch.no_grad():
+            r1 = NC.render_rays(T(rays), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True)
+        lib.nerfail_mlp_fwd_select(2)
+        with torch.no_grad():
+            r2 = NC.render_rays(T(rays), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True)
+    finally:
+        lib.nerfail_mlp_fwd_select(0)
+    for k in ('rgb_map', 'acc_map', 'rgb0', 'pts_max'):
+        assert torch.equal(r1[k].view(torch.int32), r2[k].view(torch.int32)), k

@@ -87,6 +87,46 @@ def test_training_step_gradients(golden, tag, D, W):
     assert worst <= 1.0, '\n'.join(lines)
 
 
+def test_training_step_gradients_headline_shape_on_trained_weights(golden):
+    """VERDICT r5 item 1, training half: g22 holds ONE training step (RN:776-791) of the REFERENCE on the trained D=8 W=256 pair
+    - 1 024 rays, perturbed draws, sphere colours as target - with its autograd in fp32 and in fp64. On a trained (sharp)
+    density the reference's own two precisions differ by up to 2e-3 in a fine-network parameter's gradient (importance bins
+    that flip move whole samples); per parameter that measured spread is the bound: HIP within 2 x spread + 2e-6 of the
+    reference's fp32 gradient, EVERY parameter of both networks."""
+    from conftest import trained_pair_inputs
+    from nerfail_amd import run_nerf as RN
+    from nerfail_amd.run_nerf_helpers import NeRF
+    g = golden('g22_trained_pair_d8')
+    sc, sf, rays, t_rand, u = trained_pair_inputs(g)
+    tr = g['train_pick']
+
+    def net(sd):
+        m = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.requires_grad_(True).to(dev())
+    coarse, fine = net(sc), net(sf)
+    target = T(g['train_target'])
+    r = RN.render_rays(T(rays[tr]), coarse, None, 64, N_importance=128, network_fine=fine, white_bkgd=True, perturb=1.,
+                       t_rand=T(t_rand[tr]), u=T(u[tr]))
+    loss = RN.img2mse(r['rgb_map'], target) + RN.img2mse(r['rgb0'], target)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['train_loss'])) < 1e-4 * abs(float(g['train_loss']))
+    d = np.abs(N(r['rgb_map']) - g['train_rgb_map']).max(1)
+    print('HIP training forward on g22: %d of %d rays beyond 1e-4 of the reference (median %.1e)' % (int((d > 1e-4).sum()), d.size, np.median(d)))
+    assert (d > 1e-4).sum() <= 8 and np.median(d) < 1e-6
+    worst, lines = 0.0, []
+    for nm, n_ in (('coarse', coarse), ('fine', fine)):
+        for k, p in n_.named_parameters():
+            e = l2_err(N(p.grad), g['train_%s_grad_%s' % (nm, k)])
+            spread = float(g['train_%s_referr_%s' % (nm, k)])
+            bound = 2 * spread + 2e-6
+            worst = max(worst, e / bound)
+            lines.append('%-6s %-26s err %.2e  reference fp32-vs-fp64 %.2e  bound %.2e' % (nm, k, e, spread, bound))
+    print('\n'.join(lines))
+    print('HIP training step on the trained D8 W256 pair vs the reference step: worst error / bound = %.2f' % worst)
+    assert worst <= 1.0, '\n'.join(lines)
+
+
 def test_training_loop_adam_reduces_loss():
     """RN:776-801 shape of the loop: render -> mse -> backward -> Adam.step; weights change in place, so the packed
     images must be rebuilt every step (cache keyed on parameter versions)."""

@@ -2,7 +2,7 @@
 import numpy as np
 
 import synth
-from conftest import rel_err, l2_err, trained_pair_inputs, check_against_trained_reference
+from conftest import rel_err, l2_err, trained_pair_inputs, trained_subset, check_against_trained_reference
 from oracle import nerf as O
 
 
@@ -208,8 +208,41 @@ def test_oracle_on_a_pair_trained_by_the_reference(golden):
     sc, sf, rays, t_rand, u = trained_pair_inputs(g)
     assert int(g['steps']) >= 2000 and float(g['loss_last']) < 0.05 * float(g['loss_first'])     # it really learned the scene
     n = 1024                                                           # (the numpy oracle at D=4 W=64: ~1 s per 1024 rays)
-    sub = {k: (v[:n] if getattr(v, 'shape', ()) and v.shape[:1] == (4096,) else v) for k, v in g.items()}
+    sub = trained_subset(g, n)                                         # yardsticks recounted on these n rays
     r = O.render_rays(rays[:n], sc, 64, 128, sf, white_bkgd=True, D=4, W=64)
     check_against_trained_reference(sub, 'det', r, 'oracle')
     r = O.render_rays(rays[:n], sc, 64, 128, sf, white_bkgd=True, D=4, W=64, t_rand=t_rand[:n], u=u[:n])
     check_against_trained_reference(sub, 'pert', r, 'oracle')
+
+
+def test_oracle_on_the_headline_shape_trained_pair(golden):
+    """the same at D=8 W=256 (fixture g22: a trained pair as input data, rendered by the REFERENCE in fp32
+    and fp64), on a 512-ray subset (numpy at this width: ~10 s), plus the training step's loss and gradients of g22 through the
+    float64-backward oracle on its first 64 rays - loosely: the step's 1 024-ray mean is the GPU test's job."""
+    g = golden('g22_trained_pair_d8')
+    sc, sf, rays, t_rand, u = trained_pair_inputs(g)
+    assert sc['pts_linears.1.weight'].shape == (256, 256) and int(g['weights_steps']) >= 2000
+    n = 512
+    sub = trained_subset(g, n)
+    r = O.render_rays(rays[:n], sc, 64, 128, sf, white_bkgd=True)
+    check_against_trained_reference(sub, 'det', r, 'oracle')
+    r = O.render_rays(rays[:n], sc, 64, 128, sf, white_bkgd=True, t_rand=t_rand[:n], u=u[:n])
+    check_against_trained_reference(sub, 'pert', r, 'oracle')
+
+
+def test_oracle_training_step_on_the_headline_shape_trained_pair(golden):
+    """g22 (b): one training step (RN:776-791) of the REFERENCE on the trained D=8 W=256 pair - 1 024 rays, perturbed draws,
+    its autograd in fp32 and in fp64. The float64-backward oracle is held to the reference's fp32 gradient within 2 x the
+    reference's own fp32-vs-fp64 spread + 2e-6, per parameter (measured: <= 0.36 of that bound). ~55 s of numpy."""
+    g = golden('g22_trained_pair_d8')
+    sc, sf, rays, t_rand, u = trained_pair_inputs(g)
+    tr = g['train_pick']
+    ref = O.train_step_grads(rays[tr], sc, sf, g['train_target'], t_rand=t_rand[tr], u=u[tr])
+    assert abs(ref['loss'] - float(g['train_loss'])) < 1e-5 * float(g['train_loss'])
+    worst = 0.0
+    for nm in ('coarse', 'fine'):
+        for k, v in ref['grads_' + nm].items():
+            e, spread = l2_err(v, g['train_%s_grad_%s' % (nm, k)]), float(g['train_%s_referr_%s' % (nm, k)])
+            worst = max(worst, e / (2 * spread + 2e-6))
+            assert e <= 2 * spread + 2e-6, (nm, k, e, spread)
+    print('oracle training step on g22 vs the reference: worst error / bound = %.2f' % worst)
