@@ -540,10 +540,14 @@ class gauss_net(nn.Module):
         self.update_epsilon_3d = True
         self.deterministic = True    # backward = gather-reduce over a cached inverted index (False: float atomics)
         # The reference re-runs the classifier on the unperturbed images in EVERY forward (GN:157) although they never
-        # change during an attack. True: keep the logits per (image tensor, version) - SURVEY 8f N4. Off by default
-        # (a classifier in train() mode, e.g. with dropout, is not a pure function of its input).
-        self.cache_ori_cla = False
+        # change during an attack. None (default, round 6) = automatic: the logits are kept per set of VIEW
+        # IDS (view_ids=: stable names of views whose map and image do not change) for as long as the classifier is a pure,
+        # frozen function - every module in eval() mode (AS:281-282: model.train(False)), no parameter requiring grad
+        # (AS:284-287) - and none of its parameters / buffers was written (their (address, version) pairs are part of the
+        # key). True: also per image TENSOR (address, version) and whatever the classifier's mode. False: never.
+        self.cache_ori_cla = None
         self._ori_cla_cache = {}
+        self._ori_cla_model_key = None
         # The cold tail hands the classifier a NCHW *view* of NHWC data (GN:121-131). MIOpen has no fp32 solver for that
         # layout and falls back to naive_conv_* kernels (17 ms per 8-view forward of the 800x800 victim CNN, 73 % of an
         # attack iteration). True: same values, copied to packed NCHW first (the layout torchvision models are tuned for).
@@ -598,7 +602,9 @@ class gauss_net(nn.Module):
         self._last_ori = ori_img
         x, x_rgba = _GaussGather.apply(spatial_rgb, views, self.epsilon, self._mm() if self.update_epsilon_3d else None,
                                        self.deterministic)
-        cla, ori_cla = self.cold_tail(x_rgba, ori_img)
+        # the logits of the unperturbed images: keyed by view ids when the caller names its views (then cached by default,
+        # see cache_ori_cla); without ids the key stays the float image tensor's identity, as before
+        cla, ori_cla = self.cold_tail(x_rgba, ori_img, ori_key=self._ori_key(views) if views.view_ids is not None else None)
         return x, x_rgba, cla, ori_img, ori_cla
 
     def cold_tail(self, x_rgba, ori_img, ori_key=None):
@@ -626,7 +632,13 @@ class gauss_net(nn.Module):
                 return self.model(c3), o
             with torch.no_grad():
                 return self.model(c3), o
-        if self.cache_ori_cla:
+        use_cache = self.cache_ori_cla is True or (self.cache_ori_cla is None and ori_key is not None
+                                                   and ori_key[0] == 'ids' and self._classifier_is_frozen())
+        if use_cache:
+            mk = self._classifier_state_key()
+            if mk != self._ori_cla_model_key:            # a weight or buffer was written (or replaced): every stored logit is stale
+                self._ori_cla_cache.clear()
+                self._ori_cla_model_key = mk
             if ori_key is None:
                 o = ori_img() if callable(ori_img) else ori_img
                 ori_key = (o.data_ptr(), o._version, tuple(o.shape))
@@ -637,11 +649,35 @@ class gauss_net(nn.Module):
                     self._ori_cla_cache.clear()
                 ori_cla, o = ori_logits(False)
                 self._ori_cla_cache[ori_key] = ori_cla
-                keep = getattr(self, '_ori_keep_src', None)
-                self._ori_cla_keep = getattr(self, '_ori_cla_keep', [])[-63:] + [o if keep is None else keep]   # keeps data_ptr from being recycled
+                if ori_key[0] != 'ids':              # an address-based key: the address must not be recycled while the key lives
+                    keep = getattr(self, '_ori_keep_src', None)
+                    self._ori_cla_keep = getattr(self, '_ori_cla_keep', [])[-63:] + [o if keep is None else keep]
         else:
             ori_cla, _ = ori_logits(True)
         return cla, ori_cla
+
+    def _classifier_is_frozen(self):
+        """The automatic logit cache's precondition: the classifier is a pure function of its input and nothing is being
+        learned through it - every module in eval() mode (no dropout, no batch-norm statistics update) and no parameter
+        requiring grad (the reference's attack loops set exactly this up: AS:281-287, attack_NeRFail.py:315-321)."""
+        m = self.model
+        if not isinstance(m, nn.Module):
+            return False
+        return not any(x.training for x in m.modules()) and not any(p.requires_grad for p in m.parameters())
+
+    def _classifier_state_key(self):
+        m = self.model
+        if not isinstance(m, nn.Module):
+            return None
+        return tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
+
+    def _ori_key(self, views):
+        """Cache key of the original images' logits: the views' ids (+ how often each id's resident image was replaced), else
+        the identity of the device tensor the caller passed, else None."""
+        vids = views.view_ids
+        if vids is not None:
+            return ('ids', tuple((k_, _VIEW_ORI_EPOCH.get(k_, 0)) for k_ in (_view_key(v, views.Ns) for v in vids)))
+        return views.ori_src
 
     def attack_forward(self, spatial_rgb, weight_and_index_list, ori_img, view_ids=None):
         """The forward of one NeRFail-S step (AS:317) without what that step never uses: no `x` tensor (GN:83), no float copy
@@ -655,11 +691,8 @@ class gauss_net(nn.Module):
         views = resolve_views(s, weight_and_index_list, ori_img, view_ids, self.keep_views_resident)
         _, x_rgba, aux = hot_forward(s, views, self.epsilon, self._mm() if self.update_epsilon_3d else None, need_x=False, need_aux=True)
         x_rgba.requires_grad_(True)
-        vids = views.view_ids
-        key = (('ids', tuple((k_, _VIEW_ORI_EPOCH.get(k_, 0)) for k_ in (_view_key(v, views.Ns) for v in vids)))
-               if vids is not None else views.ori_src)
         self._ori_keep_src = getattr(views, '_ori_keep', None)
-        cla, ori_cla = self.cold_tail(x_rgba, views.ori_float, ori_key=key)
+        cla, ori_cla = self.cold_tail(x_rgba, views.ori_float, ori_key=self._ori_key(views))
         self._ori_keep_src = None
         return x_rgba, cla, ori_cla, views, aux
 

@@ -52,6 +52,15 @@ def main(out_dir):
         out['s_it%d' % it] = s.cpu().numpy()
     out['wi'] = wi.cpu().numpy()
 
+    # ---- more ranks than views (attack.py, the `hi == lo` branches of both sharded gradients): ONE view on `world` ranks -
+    # at world 2 rank 1 owns nothing and only takes part in the sum (AS:72, :304: 300 views in batches of 8 leave a last
+    # batch of 4, so at 8 GPUs four ranks take this branch)
+    lo1, hi1 = sharding.shard_range(1, rank, world)
+    g1, l1 = attack.sharded_perturbation_grad(net, s0, wi[:1].contiguous(), ori[:1].contiguous(), label)
+    b1 = attack.sharded_perturbation_grad_rgb(net, s0, wi[:1].contiguous(), ori[:1].contiguous(), label)
+    out['one_view_grad'], out['one_view_loss'], out['one_view_buf'] = g1.cpu().numpy(), float(l1), b1.cpu().numpy()
+    out['one_view_owned'] = hi1 - lo1
+
     # ---- cfg5's loop shape: nerfail_s_loop over 3 batches x 4 iterations, views named by dataset id (per-view indices
     # are built once, on the rank that owns the view in its batch's split)
     lp = PB.loop_inputs()

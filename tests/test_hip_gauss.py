@@ -720,3 +720,77 @@ def test_attack_step_reuses_cached_original_logits():
     c, _ = A.nerfail_s_step(net, s0, s0, wi.cpu(), torch.from_numpy(ori_u8), label, view_ids=ids)
     d, _ = A.nerfail_s_step(net, s0, s0, None, None, label, view_ids=ids)
     assert len(calls) == 3 and torch.equal(c, ref) and torch.equal(d, ref)
+
+
+def test_original_logits_are_cached_by_default_for_named_views():
+    """cache_ori_cla = None (the default) keeps the unperturbed images' logits per set of view ids while the
+    classifier is a frozen pure function (every module in eval() mode, no parameter requiring grad: AS:281-287) - the loop of
+    INTEGRATION.md section 1 pays ONE classifier forward per step. Identical bits to the recomputing path; invalidated by
+    train() mode, by a parameter that requires grad, by any write to a weight or buffer, and by a replaced view image; views
+    without ids are never cached by default."""
+    from nerfail_amd import GaussNet as G, attack as A
+    s0, wi, ori_u8, victim = _toy_attack(seed=77, B=3)
+    calls = []
+
+    class Counting(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x):
+            calls.append(x.shape[0])
+            return self.m(x)
+    model = Counting(victim)
+    model.train(False)                                            # AS:281
+    net = G.gauss_net(dev(), 0.02, model, 'my_model', epsilon=None)
+    assert net.cache_ori_cla is None
+    label = torch.tensor(1, device=dev())
+    ori_d = torch.from_numpy(ori_u8).to(dev())
+    ids = [('r6', i) for i in range(3)]
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()
+    net.cache_ori_cla = False
+    ref, ref_loss = A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)
+    ref5 = net(s0, wi, ori_d, view_ids=ids)
+    net.cache_ori_cla = None
+    calls.clear()
+    a, la = A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)            # computes + stores
+    b, lb = A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)            # reuses
+    assert calls == [3, 3, 3] and torch.equal(a, ref) and torch.equal(b, ref) and float(la) == float(lb) == float(ref_loss)
+    calls.clear()
+    got5 = net(s0, wi, ori_d, view_ids=ids)                                          # the reference-shaped 5-tuple forward too
+    assert calls == [3] and all(torch.equal(x, y) for x, y in zip(got5, ref5))
+    calls.clear()
+    A.nerfail_s_step(net, s0, s0, wi, ori_d, label)                                  # no ids: never cached by default
+    A.nerfail_s_step(net, s0, s0, wi, ori_d, label)
+    assert calls == [3, 3, 3, 3]
+    # a subset / another order of the same views is another key
+    calls.clear()
+    A.nerfail_s_step(net, s0, s0, wi[:2].contiguous(), ori_d[:2].contiguous(), label, view_ids=ids[:2])
+    assert calls == [2, 2]
+    # train() mode: not a pure function (dropout, batch-norm statistics) -> recomputed every step
+    model.train(True)
+    calls.clear()
+    A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)
+    assert calls == [3, 3]
+    model.train(False)
+    calls.clear()
+    A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)
+    assert calls == [3]                                                               # still valid: nothing was written
+    # a weight written in place (an optimizer step, load_state_dict): every stored logit is stale
+    with torch.no_grad():
+        victim[4].weight.mul_(1.5)
+    calls.clear()
+    c, _ = A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)
+    assert calls == [3, 3]
+    net.cache_ori_cla = False
+    c_ref, _ = A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)
+    assert torch.equal(c, c_ref)
+    net.cache_ori_cla = None
+    # a parameter that requires grad: something is being learned through the classifier -> no caching
+    victim[4].weight.requires_grad_(True)
+    calls.clear()
+    A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)
+    A.nerfail_s_step(net, s0, s0, wi, ori_d, label, view_ids=ids)
+    assert calls == [3, 3, 3, 3]
+    victim[4].weight.requires_grad_(False)
+    G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()

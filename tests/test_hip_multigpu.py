@@ -35,6 +35,7 @@ def test_attack_step_two_ranks_identical_and_equal_to_one_rank(runs):
         assert np.array_equal(two[0]['s_it%d' % it], two[1]['s_it%d' % it]), it
     assert np.array_equal(two[0]['grad0'], two[1]['grad0'])
     scale = np.abs(one['grad0']).max()
+    assert scale > 1e-6                                                       # a real gradient (tests/mgpu/problem.py)
     assert np.abs(two[0]['grad0'] - one['grad0']).max() <= 1e-5 * scale       # 2-rank sum == 1-rank gradient
     assert abs(two[0]['loss0'] - one['loss0']) <= 1e-5 * abs(one['loss0'])
     # sequential iterates: sign() may flip only where |grad| is at rounding level
@@ -46,6 +47,22 @@ def test_attack_step_two_ranks_identical_and_equal_to_one_rank(runs):
     assert np.array_equal(s[..., 3], a['s0'][..., 3])                          # alpha untouched
     assert np.abs(s[..., :3] - a['s0'][..., :3]).max() <= PB.EPS
     assert (s[..., :3][a['s0'][..., 3] == 0] == 0).all()
+
+
+def test_more_ranks_than_views(runs):
+    """B < world on the HIP path. One view on two ranks: rank 1 owns no view, contributes zeros and only
+    takes part in the sum; both ranks end bit-identical, and - a sum with zeros - bit-identical to the 1-rank gradient, for
+    sharded_perturbation_grad ([P,H,W,4] + loss) and sharded_perturbation_grad_rgb (3 Ns + 1 floats, loss in the tail)."""
+    one, two = runs
+    assert [int(t['one_view_owned']) for t in two] == [1, 0] and int(one['one_view_owned']) == 1
+    for k in ('one_view_grad', 'one_view_buf'):
+        assert np.array_equal(two[0][k], two[1][k]), k
+        assert np.array_equal(two[0][k], one[k]), k
+        assert np.abs(one[k]).max() > 1e-6, k                              # a real gradient
+    assert float(two[0]['one_view_loss']) == float(two[1]['one_view_loss']) == float(one['one_view_loss'])
+    n3 = one['one_view_buf'].size - 1
+    assert one['one_view_buf'][n3] == np.float32(one['one_view_loss'])      # the loss travels in the buffer's tail
+    assert np.array_equal(one['one_view_buf'][:n3].reshape(-1, 3), one['one_view_grad'].reshape(-1, 4)[:, :3])
 
 
 def test_cfg5_loop_shape_two_ranks(runs):

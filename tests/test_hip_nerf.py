@@ -395,6 +395,39 @@ def test_lds_streaming_kernel_equals_register_streamed_kernel():
         lib.nerfail_mlp_fwd_select(0)
 
 
+@pytest.mark.parametrize('D,skips', [(8, [4]), (8, [3]), (8, []), (6, [2]), (6, [3]), (4, [1]), (4, [2]), (2, [])])
+def test_vgpr_form_kernel_all_depths_and_skip_positions(D, skips):
+    """the W = 256 inference kernel keeps one activation array in arch VGPRs and issues its MFMAs by inline asm
+    (mlp_lds.hip, lds_part<.., VG>); the (4, 64) case of the test above is NT = 2 and never compiles that form. Here every
+    instantiation that does - nerf_mlp_fwd_lds_kernel<8, SKIP, false>, SKIP = 0 / 1 / 2 (no skip; skip into the first / the
+    second layer of a pair) - at every even depth the ring covers: bitwise equal to the register-streamed kernel (all
+    MFMAs compiler-issued) and within 1e-4 of the oracle. tools/check_mfma_hazards.py checks the same code object statically."""
+    from nerfail_amd import _lib
+    from nerfail_amd.run_nerf import _mlp_points
+    from nerfail_amd.run_nerf_helpers import NeRF
+    lib = _lib.load()
+    rs = np.random.RandomState(100 + 10 * D + (skips[0] if skips else 9))
+    sd = synth.nerf_state_dict(D=D, W=256, skips=tuple(skips), seed=200 + D)
+    net = NeRF(D=D, W=256, input_ch=63, input_ch_views=27, output_ch=5, skips=list(skips), use_viewdirs=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.requires_grad_(False).to(dev())
+    R, Ns = 1031, 64                                     # 2 062 tiles: two rounds of the persistent grid + a ragged last round
+    pts = rs.uniform(-3, 3, size=(R, Ns, 3)).astype(np.float32)
+    vd = rs.normal(size=(R, 3)).astype(np.float32)
+    vd /= np.linalg.norm(vd, axis=1, keepdims=True)
+    out = {}
+    try:
+        for which in (1, 2):
+            lib.nerfail_mlp_fwd_select(which)
+            out[which] = _mlp_points(net, T(pts), T(vd))
+    finally:
+        lib.nerfail_mlp_fwd_select(0)
+    assert torch.equal(out[1].view(torch.int32), out[2].view(torch.int32))
+    n = 64
+    ref = O.run_network(sd, pts[:n], vd[:n], D=D, W=256, skips=tuple(s_ for s_ in skips if s_ < D - 1))
+    assert rel_err(N(out[2][:n]), ref) < 1e-4
+
+
 def test_lds_training_forward_saves_the_same_bits_as_the_register_kernel():
     """Round 3: the training forward runs on the LDS-ring kernel too (mlp_lds.hip, TRAIN). Everything it saves for the
     backward - encodings, every layer's post-ReLU tile, the feature tile, the views tile, the ReLU bit masks - and `raw`

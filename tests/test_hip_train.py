@@ -300,8 +300,10 @@ def test_joint_backward_equals_separate_launches(golden):
         assert l2_err(N(a), 2.0 * N(b)) < 2e-6
 
 
-@pytest.mark.parametrize('R0,R1', [(64, 0), (20, 37), (3, 1), (128, 384)])
-def test_lds_ring_backward_data_stores_the_same_bits_as_the_register_kernel(R0, R1):
+@pytest.mark.parametrize('R0,R1,N0', [(64, 0, 64), (20, 37, 64), (3, 1, 64), (128, 384, 64),
+                                      (5, 0, 37), (1, 0, 31), (33, 0, 97),          # M % 32 != 0 - the `sraw < a.M` padding path
+                                      (600, 0, 64), (300, 300, 64)])                # more tiles than 4 x 256 per network: several rounds
+def test_lds_ring_backward_data_stores_the_same_bits_as_the_register_kernel(R0, R1, N0):
     """Round 5: nerfail_mlp_bwd_data2 runs nerf_mlp_bwd_data_lds_kernel at W = 256 (the transposed image through the LDS weight
     ring, dZ formed lazily from the ReLU bits where it is consumed and stored from there, one network per workgroup). Every
     stored dZ - all layers, both networks of a joint launch, ragged last tiles, fewer tiles than waves - must be BITWISE what the
@@ -311,13 +313,14 @@ def test_lds_ring_backward_data_stores_the_same_bits_as_the_register_kernel(R0, 
     _, n0 = hip_nerf(8, 256, 61, requires_grad=True)
     _, n1 = hip_nerf(8, 256, 62, requires_grad=True)
     rs = np.random.RandomState(R0 + R1)
-    N0, N1 = 64, 192
+    N1 = 192
     M0, M1 = R0 * N0, R1 * N1
     M0 = (M0 + 31) // 32 * 32 if M1 else M0                    # (a joint launch needs whole tiles of the first network)
     vd = torch.nn.functional.normalize(T(rs.normal(size=(max(R0, R1, 1), 3)).astype(np.float32)), dim=-1)
     acts = torch.empty((_train.acts_floats(n0, M0) + (_train.acts_floats(n1, M1) if M1 else 0),), device=dev())
     nA = _train.acts_floats(n0, M0)
     R0e = M0 // N0
+    assert R0e * N0 == M0 and (M1 > 0 or N0 == 64 or M0 % 32 != 0)
     _train.mlp_fwd_train(n0, T(rs.normal(size=(R0e, N0, 3)).astype(np.float32)), vd[:R0e].contiguous(), acts=acts[:nA])
     if M1:
         _train.mlp_fwd_train(n1, T(rs.normal(size=(R1, N1, 3)).astype(np.float32)), vd[:R1].contiguous(), acts=acts[nA:])

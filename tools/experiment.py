@@ -33,7 +33,7 @@ EXPERIMENTS = {
     # round 4, K11: the per-wave LDS slice doubled = half the waves per CU (how much does the segmented reduce depend on occupancy?)
     'seg_lds2': ('gauss_csr.hip', [], ['-DNF_SEG_LDS_MULT=2']),
     # (the round-2/3 ablations of the old entry-strided reduce - seg_noscan / _nogather / _noemit / _u16 / _u4 - went with that kernel)
-    'k10_late_index': ('gauss.hip', [], ['-DNF_K10_EARLY_INDEX=0']),
+    'k10_early_index': ('gauss.hip', [], ['-DNF_K10_EARLY_INDEX=1']),   # (until round 6: 'k10_late_index' with =0, the product default)
     'lds_base': ('mlp_lds.hip', [], []),
     'lds_gpm2': ('mlp_lds.hip', [], ['-DNF_LDS_GPM=2']),
     'lds_noenc': ('mlp_lds.hip', [('        encode_sample(a, s, hh, emb, demb);\n',
