@@ -163,8 +163,16 @@ def check_against_trained_reference(g, tag, got, who):
     lines = []
     for k in ('rgb0', 'acc0', 'disp0'):
         e = rel_err(got[k], g['%s_%s' % (tag, k)])
-        lines.append('%s %s coarse %-5s rel err %.1e' % (who, tag, k, e))
-        assert e < 1e-4, lines
+        # Where the fixture also holds the reference's fp64 value of this output (g22), the bound is never below the reference's
+        # OWN fp32-vs-fp64 distance in the same measure: on g22's trained scene 2 378 of 4 096 rays cross empty space only, acc0
+        # ~ 1e-3 there is a sum of 64 terms 1 - exp(-sigma delta) that cancel to ~1e-5 each (RN:288), and the reference's two
+        # precisions differ by 1.1e-3 (det) / 1.8e-3 (pert) of such a value - a 1e-4 bound would be held by no implementation,
+        # the reference's own fp32 run included. (rgb0, disp0: the reference's spread is ~1e-5; the bound stays 1e-4.)
+        bound = 1e-4
+        if '%s_f64_%s' % (tag, k) in g:
+            bound = max(bound, rel_err(g['%s_%s' % (tag, k)], g['%s_f64_%s' % (tag, k)]))
+        lines.append('%s %s coarse %-5s rel err %.1e (bound %.1e)' % (who, tag, k, e, bound))
+        assert e < bound, lines
     d = np.abs(np.asarray(got['rgb_map'], np.float64) - g[tag + '_rgb_map']).max(1)
     da = np.abs(np.asarray(got['acc_map'], np.float64) - g[tag + '_acc_map'])
     over = int(((d > 1e-4) | (da > 1e-4)).sum())

@@ -1008,8 +1008,7 @@ def g22():
                 torch.rand = orig
         for k in keys:
             out['%s_%s' % (tag, k)] = res['f32'][k].numpy()
-            if k in ('rgb_map', 'acc_map', 'rgb0'):
-                out['%s_f64_%s' % (tag, k)] = res['f64'][k].numpy().astype(np.float32)
+            out['%s_f64_%s' % (tag, k)] = res['f64'][k].numpy().astype(np.float32)
         d = (res['f32']['rgb_map'].double() - res['f64']['rgb_map']).abs().max(1)[0].numpy()
         da = (res['f32']['acc_map'].double() - res['f64']['acc_map']).abs().numpy()
         d0 = (res['f32']['rgb0'].double() - res['f64']['rgb0']).abs().max(1)[0].numpy()

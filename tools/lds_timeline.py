@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Reads the wall-clock stamps of the `lds_timeline` experiment build (tools/experiment.py lds_timeline): where a SMALL launch of
+the LDS-ring forward kernel (the training step's 2 and 6 tiles per wave) spends its time - launch skew across the grid, the
+constant load, the ring start, every round's tile, the drain - against the HIP-event time of the same launch.
+
+    python3 tools/lds_timeline.py [RxN ...]        (default 1024x64 1024x192 4096x192)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+from nerfail_amd import _lib  # noqa: E402
+_lib.LIB_PATH = os.path.join(ROOT, 'nerfail_amd', 'lib', 'libnerfail_hip_exp_lds_timeline.so')
+import synth  # noqa: E402
+from nerfail_amd import _train  # noqa: E402
+from nerfail_amd.run_nerf import _mlp_points  # noqa: E402
+from nerfail_amd.run_nerf_helpers import NeRF  # noqa: E402
+
+dev = torch.device('cuda:0')
+sd = synth.nerf_state_dict(seed=1)
+m = NeRF(8, 256, 63, 27, 5, [4], True)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+m = m.to(dev)
+TICK_US = 0.01                                           # s_memrealtime: 100 MHz
+
+for sz in (sys.argv[1:] or ['1024x64', '1024x192', '4096x192']):
+    R, N = [int(v) for v in sz.split('x')]
+    pts = torch.randn((R, N, 3), device=dev)
+    vd = torch.nn.functional.normalize(torch.randn((R, 3), device=dev), dim=-1)
+    for name, fn in (('inference', lambda: _mlp_points(m, pts, vd)), ('training forward', lambda: _train.mlp_fwd_train(m, pts, vd)[0])):
+        for _ in range(3):
+            raw = fn()
+        torch.cuda.synchronize()
+        ev = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            raw = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ev.append(e0.elapsed_time(e1) * 1e3)
+        ntiles = (R * N + 31) // 32
+        waves = min(1024, (ntiles + 3) // 4 * 4)
+        rounds = (ntiles + 1023) // 1024
+        w = raw.reshape(-1).view(torch.int64)[:waves * 16].reshape(waves, 16).cpu().numpy()
+        t0 = w[:, 0].min()
+        us = lambda a: (a - t0) * TICK_US
+        print('== %s %s: %d tiles, %d waves, %d round(s); HIP events %.1f us (median of 5, min %.1f)' % (name, sz, ntiles, waves, rounds, np.median(ev), min(ev)))
+        print('   kernel entry        : first 0.0, median %.1f, last %.1f us' % (np.median(us(w[:, 0])), us(w[:, 0]).max()))
+        print('   constants in LDS    : +%.1f us (median per wave), ring started +%.1f us' % (np.median((w[:, 1] - w[:, 0]) * TICK_US), np.median((w[:, 2] - w[:, 1]) * TICK_US)))
+        prev = w[:, 2]
+        for r in range(min(rounds, 12)):
+            d = (w[:, 3 + r] - prev) * TICK_US
+            print('   tile of round %-2d    : median %.1f us, fastest %.1f, slowest %.1f   (ideal 9280 MFMA x 64 cycles at 2.4 GHz = 247.5 us)' % (r, np.median(d), d.min(), d.max()))
+            prev = w[:, 3 + r]
+        print('   drain               : +%.1f us (median); kernel end first %.1f, median %.1f, last %.1f us after the first entry' % (
+            np.median((w[:, 15] - prev) * TICK_US), us(w[:, 15]).min(), np.median(us(w[:, 15])), us(w[:, 15]).max()))
+        per_cu = us(w[:, 15]).reshape(-1, 4).max(1)
+        print('   slowest 5 workgroups end at %s us' % np.round(np.sort(per_cu)[-5:], 1))
