@@ -156,7 +156,7 @@ def contract_line(detail, world, args, detail_path):
     }
     # optional keys, most important first (dropped from the END when the line is too long)
     tr, at = detail.get('train') or {}, detail.get('attack') or {}
-    gp = at.get('gauss_path_deterministic') or {}
+    gp = at.get('gauss_path_fused_step') or at.get('gauss_path_deterministic') or {}    # N = 1: the sign step fused into K11 (round 6)
     opt = [
         ('fwd_bwd_rays_per_sec', _num(tr.get('train_rays_per_sec_fwd_bwd'))),
         ('fwd_bwd_ms_per_step', _num(tr.get('ms_per_step'))),

@@ -271,11 +271,13 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     opt = Adam(params, lr=5e-4, betas=(0.9, 0.999))              # RN:207 on the fused K13 kernel
     focal, K = synth.lego_intrinsics(H, W)
     c2w = synth.pose_spherical(-180., -30., 4.)[:3, :4]
-    all_rays = ray_gen(H, W, K, c2w, 2., 6.)
     gen = torch.Generator(device=dev).manual_seed(0)
     host_rng = np.random.default_rng(0)
 
     def step():
+        # RN:752: get_rays of the step's view on the FULL image, inside the step as in the reference's loop (round 6, VERDICT r5
+        # item 2: until then the rays came from an all_rays tensor made before the timed region) - one ray_gen launch, 28 MB
+        all_rays = ray_gen(H, W, K, c2w, 2., 6.)
         # RN:768 draws the batch with the LEGACY np.random.choice(H*W, N_rand, replace=False): a 640 000-element host
         # permutation (6-15 ms, longer than the whole GPU step). Same distribution from numpy's Generator.choice (Floyd's
         # algorithm: 27 us on the host, which runs ahead of the GPU anyway); the 4 KB of indices go up asynchronously.
@@ -346,9 +348,9 @@ def train_bench(dev, steps=10, warmup=2, n_rand=1024, precision='f32'):
     out = {'train_rays_per_sec_fwd_bwd': n_rand / dt, 'ms_per_step': dt * 1e3, 'rays_per_step': n_rand, 'precision': precision,
            'final_loss': float(loss.detach()), 'fp32_equivalent_tflops_whole_step': flop / dt / 1e12,
            'statistic': 'median of the %d timed steps' % steps, 'ms_per_step_mean_whole_loop': mean_dt * 1e3, 'warmup': warmup_info,
-           'note': 'kernel metric: the step omits the reference loop\'s per-iteration HOST work - get_rays on the full image '
-                   '(RN:752); the batch is drawn on the host like RN:768 but with numpy Generator.choice (27 us) instead of the '
-                   'legacy np.random.choice (a 6-15 ms permutation); rays are gathered from a precomputed all_rays',
+           'note': 'the whole loop body RN:752-801: get_rays of the full 800x800 image (one ray_gen launch) -> batch of 1024 pixels '
+                   '(drawn on the host like RN:768, but with numpy Generator.choice (27 us) instead of the legacy np.random.choice, '
+                   'a 6-15 ms permutation) -> render -> loss -> backward -> Adam',
            'ms_per_step_each': [round(v, 3) for v in per_step]}
     if precision == 'f32':      # the three GEMM families run on the exact-f32 MFMA: that pipe bounds the step
         out['roofline'] = {'bound': 'mfma', 'achieved': flop / dt / 1e12, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -536,7 +538,18 @@ def attack_bench(dev, iters=5, out=None):
         hot_backward_rgb(aux, G, views, buf)
         return igsm_step_rgb(s, buf, s_init, 2.0, 32.0, False)
     out['gauss_path_deterministic'] = leg(timed(one_iter_rgb, s_init.clone()))
-    out['gauss_path_deterministic']['form'] = 'rgb-gradient-only step path (attack.nerfail_s_step): K10 no-x/uint8-ori/aux, K11 rgb, K12 rgb'
+    out['gauss_path_deterministic']['form'] = ('rgb-gradient-only step path with the gradient materialised (attack.nerfail_s_step on more '
+                                               'than one rank: the [Ns,3] buffer is what the all-reduce moves): K10 no-x/uint8-ori/aux, K11 rgb, K12 rgb')
+
+    # (1b) round 6: the path nerfail_s_step takes on ONE rank - the sign step is the epilogue of K11's last launch
+    # (nerfail_gauss_bwd_views_rgb_step): no [Ns,3] gradient written and read back, one launch less; bit-identical iterates
+    from nerfail_amd.GaussNet import hot_backward_rgb_step
+
+    def one_iter_fused(s):
+        _, x_rgba, aux = hot_forward(s, views, None, None, need_x=False, need_aux=True)
+        return hot_backward_rgb_step(aux, G, views, s, s_init, 2.0, 32.0, False)
+    out['gauss_path_fused_step'] = leg(timed(one_iter_fused, s_init.clone()))
+    out['gauss_path_fused_step']['form'] = 'attack.nerfail_s_step on one rank: K10, then K11 with the sign step K12 as its epilogue'
 
     # (2) the full autograd form (all four gradient channels, x materialised): what gauss_net.forward + loss.backward() run
     for det in (True, False):
@@ -604,6 +617,12 @@ def attack_bench(dev, iters=5, out=None):
     rl['compulsory_bytes_per_iter'] = comp
     rl['frac_compulsory'] = comp / (out['gauss_path_deterministic']['ms_per_iter'] * 1e-3) / 1e9 / HBM_PEAK_GBS
     out['gauss_path_deterministic'] = dict(out['gauss_path_deterministic'], roofline=rl)
+    # the fused form: K11 writes no [Ns,3] gradient, the step reads s and s_init and writes s' (K12's bytes without the gradient read)
+    comp_f = comp - Ns * 12 - Ns * 12
+    rl = dict(out['gauss_path_fused_step']['roofline'])
+    rl['compulsory_bytes_per_iter'] = comp_f
+    rl['frac_compulsory'] = comp_f / (out['gauss_path_fused_step']['ms_per_iter'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out['gauss_path_fused_step'] = dict(out['gauss_path_fused_step'], roofline=rl)
     if light:
         out['batch_views'] = B
         return out
@@ -725,7 +744,7 @@ def gauss_kernel_rooflines(dev, wi, ori, s_init, G, n=10):
         'K11_gauss_bwd_views': (lambda: lib.nerfail_gauss_bwd_views_rgb(_lib.dev(aux_a), _lib.dev(aux_m), _lib.dev(G), table, B, Ns, P,
                                                                        _lib.dev(scratch), _lib.dev(g3), st),
                                 k11, B * 81.9e6, ('gauss_pixel_grad_rgb_kernel', 'gauss_seg_reduce_views_kernel<false>', 'gauss_seg_combine_views_kernel',
-                                                  'gauss_rows_sum3_kernel')),
+                                                  'gauss_rows_sum3_kernel<false>')),
         'K12_igsm_step': (k12_call, k12, 122.9e6, ('igsm_step_rgb_kernel',)),
     }
     out = {}

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NERFAIL_ABI_VERSION 6
+#define NERFAIL_ABI_VERSION 7
 
 #define NERFAIL_OK 0
 #define NERFAIL_EINVAL 1   /* bad argument (null pointer, size, unsupported shape) */
@@ -365,6 +365,15 @@ int nerfail_gauss_bwd_views(const float* ori_img, const float* x, const float* g
 int nerfail_gauss_bwd_views_rgb(const float* aux_alpha, const unsigned char* aux_mask, const float* grad_x_rgba,
                                 const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float* scratch,
                                 float* grad_rgb, void* stream);
+/* ABI 7 (round 6). The same backward with the NeRFail-S sign step (AS:352-392 = nerfail_igsm_step_rgb) as the epilogue of its last
+ * launch: spatial_out[j] = step(spatial[j], d CE / d spatial_rgb[j], spatial_init[j]) - for a 1-rank run, where the gradient is
+ * not all-reduced, it is then neither written nor read back (23 MB each way) and one launch goes. grad_rgb: NULL, or [Ns,3] to
+ * receive the gradient as well (required when n_views > 16: the running sum between launches). Same sums in the same order as
+ * nerfail_gauss_bwd_views_rgb + nerfail_igsm_step_rgb: bit-identical spatial_out. spatial_out must not alias an input. */
+int nerfail_gauss_bwd_views_rgb_step(const float* aux_alpha, const unsigned char* aux_mask, const float* grad_x_rgba,
+                                     const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float* scratch,
+                                     float* grad_rgb, const float* spatial, const float* spatial_init, float a, float epsilon,
+                                     int targeted, float* spatial_out, void* stream);
 /* ONE view, n_rhs (1..8) upstream gradients at once - the class-logit gradients of one DeepFool iteration (deepfool.py:
  * 66-96 takes them one autograd.grad call at a time). grad_x_rgba: [n_rhs][P,4]; grad_spatial: [n_rhs][Ns,4],
  * overwritten. Sums run in the same order as nerfail_gauss_bwd_views, so each right-hand side gets bitwise the result of

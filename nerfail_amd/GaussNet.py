@@ -470,6 +470,26 @@ def hot_backward_rgb(aux, grad_x_rgba, views, out=None):
     return out
 
 
+def hot_backward_rgb_step(aux, grad_x_rgba, views, spatial, spatial_init, a, epsilon, targeted, grad_out=None):
+    """K11 (rgb form) + K12 in one pass (nerfail_gauss_bwd_views_rgb_step, round 6): the new perturbation table after the sign step
+    AS:352-392; the gradient itself is written only if `grad_out` (>= 3 Ns floats) is given. Bit-identical to hot_backward_rgb
+    followed by attack.igsm_step_rgb."""
+    dev = grad_x_rgba.device
+    Ns = views.Ns
+    table, floats = view_table(views.indices())
+    scratch = torch.empty((floats,), dtype=torch.float32, device=dev)
+    s, s0 = _lib.f32c(spatial, dev), _lib.f32c(spatial_init, dev)
+    if s.numel() != 4 * Ns or s0.numel() != 4 * Ns:
+        raise ValueError('spatial / spatial_init must hold Ns = %d rows of 4 floats' % Ns)
+    if grad_out is None and views.B > 16:
+        grad_out = torch.empty((3 * Ns,), dtype=torch.float32, device=dev)
+    out = torch.empty_like(s)
+    _lib.check(_lib.load().nerfail_gauss_bwd_views_rgb_step(_lib.dev(aux[0]), _lib.dev(aux[1]), _lib.dev(_lib.f32c(grad_x_rgba)), table, views.B,
+                                                           Ns, views.P, _lib.dev(scratch), _lib.dev(grad_out), _lib.dev(s), _lib.dev(s0),
+                                                           float(a), float(epsilon), int(bool(targeted)), _lib.dev(out), _lib.stream()))
+    return out
+
+
 class _GaussGather(torch.autograd.Function):
     """x, x_rgba = f(spatial_rgb); d/d(spatial_rgb) by the hand-written backward. The views carry no grad.
 
@@ -539,6 +559,8 @@ class gauss_net(nn.Module):
         self.epsilon = epsilon
         self.update_epsilon_3d = True
         self.deterministic = True    # backward = gather-reduce over a cached inverted index (False: float atomics)
+        self.rgb_grad_only = True    # nerfail_s_step: rgb-gradient-only step path (False: full autograd path, four channels)
+        self.fused_sign_step = True  # nerfail_s_step on ONE rank: the sign step as the epilogue of the gather backward (round 6)
         # The reference re-runs the classifier on the unperturbed images in EVERY forward (GN:157) although they never
         # change during an attack. None (default, round 6) = automatic: the logits are kept per set of VIEW
         # IDS (view_ids=: stable names of views whose map and image do not change) for as long as the classifier is a pure,

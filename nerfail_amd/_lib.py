@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: libnerfail_hip.so binds to 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NERFAIL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnerfail_hip.so')   # override: A/B builds (tools/ablate.py)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_DEPTH = 16
 DW_BF16X3, DW_ACCUMULATE = 1, 2          # flags of nerfail_mlp_bwd_weights
 RAY_FLOATS = 11
@@ -89,6 +89,7 @@ SIGNATURES = {
     'nerfail_gauss_fwd_views': (c_i, [c_p, c_i64, c_p, c_i, c_i64, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nerfail_gauss_bwd_views_rgb': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i64, c_i64, c_p, c_p, c_p]),
     'nerfail_igsm_step_rgb': (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_i, c_p, c_p]),
+    'nerfail_gauss_bwd_views_rgb_step': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i64, c_i64, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p]),
     'nerfail_fingerprint': (c_i, [c_p, c_i64, c_i64, c_p, c_p]),
     'nerfail_gauss_csr_workspace_bytes': (ctypes.c_size_t, [c_i64, c_i64, c_i64]),
     'nerfail_gauss_csr_build': (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),

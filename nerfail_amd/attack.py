@@ -131,11 +131,29 @@ def sharded_perturbation_grad(net, spatial, weight_and_index, ori_img, label, gr
     return g, loss
 
 
+def perturbation_step_rgb(net, spatial, spatial_init, weight_and_index, ori_img, label, a, epsilon, targeted, view_ids=None):
+    """One rank, no collective: forward, CE, classifier backward, then the gather backward with the sign step AS:352-392 as its
+    epilogue (GaussNet.hot_backward_rgb_step) - the [Ns,3] gradient is never materialised. Returns (new perturbation, loss);
+    bit-identical to perturbation_grad_rgb + igsm_step_rgb."""
+    from .GaussNet import hot_backward_rgb_step
+    xr, cla, ori_cla, views, aux = net.attack_forward(spatial, weight_and_index, ori_img, view_ids)
+    lab = label.to(cla.device).broadcast_to([cla.shape[0]])
+    loss = torch.nn.functional.cross_entropy(cla, lab, reduction='sum') / float(cla.shape[0])
+    loss.backward()
+    return hot_backward_rgb_step(aux, xr.grad, views, spatial, spatial_init, a, epsilon, targeted), loss.detach()
+
+
 def nerfail_s_step(net, spatial, spatial_init, weight_and_index, ori_img, label, a=2.0, epsilon=32.0,
                    targeted=False, group=None, timing=None, view_ids=None):
     """One NeRFail-S iteration (AS:304-392) on one batch of views. Sharded over ranks when torch.distributed is up:
     every rank ends with the identical perturbation tensor."""
     if getattr(net, 'deterministic', True) and getattr(net, 'rgb_grad_only', True):
+        world, _ = sharding.world_and_rank(group)
+        if world == 1 and not sharding.force_collectives() and getattr(net, 'fused_sign_step', True):
+            if view_ids is None and getattr(weight_and_index, 'view_ids', None) is not None:
+                view_ids = weight_and_index.view_ids
+            out, loss = perturbation_step_rgb(net, spatial, spatial_init, weight_and_index, ori_img, label, a, epsilon, targeted, view_ids)
+            return out.view(spatial.shape), loss
         Ns = spatial.numel() // 4
         buf = sharded_perturbation_grad_rgb(net, spatial, weight_and_index, ori_img, label, group, timing, view_ids)
         return igsm_step_rgb(spatial, buf, spatial_init, a, epsilon, targeted), buf[3 * Ns]

@@ -587,6 +587,15 @@ struct RowsSum {
     int nv;
 };
 
+// AS:352-392 for one row (igsm_step_rgb_kernel's arithmetic, gauss.hip): the fused epilogue of the rows sum
+struct StepArgs {
+    const float4* s;
+    const float4* s_init;
+    float4* out;
+    float a, epsilon;
+    int targeted;
+};
+
 template <int C>
 __global__ __launch_bounds__(256) void gauss_rows_sum_kernel(RowsSum a, long Ns, int accumulate, float4* __restrict__ grad_spatial) {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -604,8 +613,15 @@ __global__ __launch_bounds__(256) void gauss_rows_sum_kernel(RowsSum a, long Ns,
     }
 }
 
-// the same sum written as [Ns,3] (rgb only): the buffer the perturbation-gradient all-reduce moves (23 MB instead of 30.7)
-__global__ __launch_bounds__(256) void gauss_rows_sum3_kernel(RowsSum a, long Ns, int accumulate, float* __restrict__ grad3) {
+// the same sum written as [Ns,3] (rgb only): the buffer the perturbation-gradient all-reduce moves (23 MB instead of 30.7).
+// Round 6, STEP: the NeRFail-S sign step (AS:352-392) as the epilogue - one launch less, and the gradient is neither written nor read
+// back (world == 1: nothing is all-reduced); grad3 may be NULL then. 8 us of a 0.265 ms iteration.
+// (Measured and dropped in the same round: resolving the rows that cross chunk boundaries HERE - a marker in the unused fourth
+// channel of the row sums, the records added up by the thread that needs the row - instead of in gauss_seg_combine_views_kernel
+// (8.5 us + a launch). Bit-identical, but only ~0.4 % of the rows are split and still nearly every 64-row WAVE holds one: the
+// whole wave walks the record path and this kernel went from 24 to 48 us.)
+template <bool STEP>
+__global__ __launch_bounds__(256) void gauss_rows_sum3_kernel(RowsSum a, long Ns, int accumulate, float* __restrict__ grad3, StepArgs st) {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= Ns) return;
     int p[kViewsPerLaunch];
@@ -615,7 +631,23 @@ __global__ __launch_bounds__(256) void gauss_rows_sum3_kernel(RowsSum a, long Ns
 #pragma unroll
     for (int v = 0; v < kViewsPerLaunch; ++v)
         if (p[v] >= 0) s = f4_add(s, a.val[v][p[v]]);
-    grad3[3 * j] = s.x; grad3[3 * j + 1] = s.y; grad3[3 * j + 2] = s.z;
+    if (grad3 != nullptr) { grad3[3 * j] = s.x; grad3[3 * j + 1] = s.y; grad3[3 * j + 2] = s.z; }
+    if constexpr (STEP) {
+        const float4 v = st.s[j], in = st.s_init[j];
+        const float sv[3] = {v.x, v.y, v.z}, gv[3] = {s.x, s.y, s.z}, iv[3] = {in.x, in.y, in.z};
+        float r[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float sg = (gv[c] > 0.f) ? 1.f : ((gv[c] < 0.f) ? -1.f : 0.f);
+            const float stp = __fmul_rn(st.a, sg);
+            float q = st.targeted ? __fsub_rn(sv[c], stp) : __fadd_rn(sv[c], stp);
+            q = (v.w > 0.f) ? q : 0.f;
+            q = fmaxf(q, __fsub_rn(iv[c], st.epsilon));
+            q = fminf(q, __fadd_rn(iv[c], st.epsilon));
+            r[c] = q;
+        }
+        st.out[j] = make_float4(r[0], r[1], r[2], v.w);
+    }
 }
 
 // Row ordinals of a view index: pos[j] = number of non-empty rows before row j, or -1 for an empty row; n_rows = number
@@ -890,7 +922,8 @@ extern "C" size_t nerfail_gauss_bwd_views_scratch_floats(const nerfail_view_inde
 // steps 2 + 3 of the batched backward: every view's entries -> its own row sums (one launch for up to 16 views), then the
 // views' sums added per row in view order, into [Ns,4] (grad4) or [Ns,3] (grad3)
 static int reduce_views(const nerfail_view_index* views, int n_views, long Ns, long P, float* scratch, float* grad4, float* grad3,
-                        hipStream_t s) {
+                        hipStream_t s, const StepArgs* step = nullptr) {
+    const bool rgb = grad3 != nullptr || step != nullptr;
     const long n = (long)n_views * P;
     float* cursor = scratch + (size_t)n * 4;
     for (int v0 = 0; v0 < n_views; v0 += kViewsPerLaunch) {
@@ -915,14 +948,19 @@ static int reduce_views(const nerfail_view_index* views, int n_views, long Ns, l
         a.total_blocks = 0;
         for (int i = 0; i < kViewsPerLaunch; ++i) { a.block_start[i] = a.total_blocks; a.total_blocks += a.chunks[i] / 4; }
         if (max_chunks > 0) {
-            if (grad3 != nullptr) gauss_seg_reduce_views_kernel<false><<<dim3((unsigned)(((a.total_blocks + 7) / 8) * 8)), dim3(256), 0, s>>>(a);
+            if (rgb) gauss_seg_reduce_views_kernel<false><<<dim3((unsigned)(((a.total_blocks + 7) / 8) * 8)), dim3(256), 0, s>>>(a);
             else gauss_seg_reduce_views_kernel<true><<<dim3((unsigned)(((a.total_blocks + 7) / 8) * 8)), dim3(256), 0, s>>>(a);
             NF_LAUNCHED("gauss_seg_reduce_views_kernel");
             gauss_seg_combine_views_kernel<<<dim3((unsigned)((max_chunks + 255) / 256), (unsigned)nv), dim3(256), 0, s>>>(a);
             NF_LAUNCHED("gauss_seg_combine_views_kernel");
         }
-        if (grad3 != nullptr) {
-            gauss_rows_sum3_kernel<<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, grad3);
+        if (rgb) {
+            const bool last = v0 + kViewsPerLaunch >= n_views;
+            if (step != nullptr && last) {
+                gauss_rows_sum3_kernel<true><<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, grad3, *step);
+            } else {
+                gauss_rows_sum3_kernel<false><<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, grad3, StepArgs{});
+            }
             NF_LAUNCHED("gauss_rows_sum3_kernel");
         } else {
             gauss_rows_sum_kernel<1><<<dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s>>>(r, Ns, v0 > 0 ? 1 : 0, (float4*)grad4);
@@ -962,6 +1000,28 @@ extern "C" int nerfail_gauss_bwd_views_rgb(const float* aux_alpha, const unsigne
                                                                                         (float4*)scratch);
     NF_LAUNCHED("gauss_pixel_grad_rgb_kernel");
     return reduce_views(views, n_views, Ns, P, scratch, nullptr, grad_rgb, s);
+}
+
+// nerfail_gauss_bwd_views_rgb with the NeRFail-S sign step (nerfail_igsm_step_rgb) as the epilogue of its last launch
+extern "C" int nerfail_gauss_bwd_views_rgb_step(const float* aux_alpha, const unsigned char* aux_mask, const float* grad_x_rgba,
+                                                const nerfail_view_index* views, int n_views, int64_t Ns, int64_t P, float* scratch,
+                                                float* grad_rgb, const float* spatial, const float* spatial_init, float a, float epsilon,
+                                                int targeted, float* spatial_out, void* stream) {
+    NF_REQUIRE(Ns > 0 && P > 0 && n_views >= 1, "bad sizes");
+    NF_REQUIRE(aux_alpha && aux_mask && grad_x_rgba && views && scratch && spatial && spatial_init && spatial_out, "NULL pointer");
+    NF_REQUIRE(n_views <= kViewsPerLaunch || grad_rgb != nullptr, "more views than one launch sums need grad_rgb as the running sum");
+    NF_REQUIRE(spatial_out != spatial && spatial_out != spatial_init, "spatial_out must not alias an input");
+    for (int v = 0; v < n_views; ++v)
+        NF_REQUIRE(view_ok(views[v], Ns, P), "a view index is incomplete or inconsistent (NULL array, n_entries > 8 P, n_rows > n_entries)");
+    hipStream_t s = as_stream(stream);
+    const long n = (long)n_views * P;
+    gauss_pixel_grad_rgb_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(aux_alpha, aux_mask, (const float4*)grad_x_rgba, n,
+                                                                                        (float4*)scratch);
+    NF_LAUNCHED("gauss_pixel_grad_rgb_kernel");
+    StepArgs st;
+    st.s = (const float4*)spatial; st.s_init = (const float4*)spatial_init; st.out = (float4*)spatial_out;
+    st.a = a; st.epsilon = epsilon; st.targeted = targeted;
+    return reduce_views(views, n_views, Ns, P, scratch, nullptr, grad_rgb, s, &st);
 }
 
 // ONE view, C right-hand sides over the view's compact index: reduce -> combine -> expand through pos

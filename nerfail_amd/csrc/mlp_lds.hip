@@ -46,6 +46,13 @@ typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
 #ifndef NF_LDS_TRAIN_NEWDMA
 #define NF_LDS_TRAIN_NEWDMA 1 // 1: the training kernel on the buffer-form / per-step refill as well
 #endif
+#ifndef NF_LDS_TRAIN_SP1
+#define NF_LDS_TRAIN_SP1 1    // the training forward on the one-piece-of-side-work-per-shadow step form too (round 6; 0: round-2 form)
+#endif
+#ifndef NF_LDS_TRAIN_K0
+#define NF_LDS_TRAIN_K0 8     // first MFMA of a quad's first step whose shadow carries an activation store (4 stores: K0 .. K0 + 3;
+                              // 8: behind the fragment reads of MFMAs 4..7 - measured 6.93 -> 6.89 ms at 786 432 samples; 4: round-3 position)
+#endif
 #ifndef NF_LDS_MID_SPLIT
 #define NF_LDS_MID_SPLIT 0  // 1: the next quad's operand preparation in two halves behind two MFMAs
 #endif
@@ -91,13 +98,13 @@ struct LdsCfg {
 };
 
 // The weight stream of one workgroup. Every member but fr / gsrc / rl is wave-uniform (SGPRs).
-// SP1: the step form with ONE piece of side work per MFMA shadow (round 5; inference kernels - the training kernel's stores
-// already fill those shadows and it spills under this form).
+// SP1: the step form with ONE piece of side work per MFMA shadow (round 5: inference and backward-data kernels; round 6: the
+// training forward too - with the buffer-form refill it no longer spills: 227 VGPRs, scratch 0).
 template <int NT, bool SP1 = false, bool NEWDMA = false>
 struct WRing {
     using C = LdsCfg<NT>;
-    // NEWDMA (round 5, inference kernels): the refill as buffer_load ... lds, one DMA per step (LdsCfg::kDmaSpread). The training
-    // kernel keeps the round-2 form (global_load_lds in a burst behind the boundary step): under the new form it spills.
+    // NEWDMA (round 5): the refill as buffer_load ... lds, one DMA per step (LdsCfg::kDmaSpread). All three ring kernels use it
+    // (NF_LDS_TRAIN_NEWDMA = 0 restores the round-2 form of the training forward: global_load_lds in a burst behind the boundary step).
     static constexpr bool kBufDma = NEWDMA && NF_LDS_DMA_BUF;
     static constexpr bool kSpreadDma = NEWDMA && C::kDmaSpread;
     const float* gsrc;       // packed + lane*4: this lane's 16 bytes of stream piece 0
@@ -143,8 +150,17 @@ struct WRing {
     // Group boundary: every wave's pieces of the next group have landed (counted wait: the S-2 younger groups stay
     // in flight), every wave's reads of the group just finished have returned -> one barrier makes the first
     // readable for all and the second's slot free for all.
-    // EXTRA: vector-memory operations that are NOT LDS-DMAs (training stores) and are known to have been issued after the
-    // youngest DMA of the group that is allowed to stay in flight: vmcnt counts them all, in issue order.
+    // EXTRA: vector-memory operations that are NOT LDS-DMAs (training stores) and may stay in flight across the boundary.
+    // vmcnt retires in issue order and counts every vector-memory operation, so "vmcnt(N)" = "everything but the N youngest has
+    // completed". Call INTERVAL i the steps from boundary i (inclusive: the SYNC step that crossed it) to boundary i + 1. In
+    // interval i this wave issues exactly GPW refill DMAs - the pieces of group i + 2 into the slot boundary i freed - whatever the
+    // refill form: burst (all GPW behind the first MFMAs of the SYNC step) or spread (kSpreadDma: DMA J behind MFMA 0 of step J,
+    // J = 0 .. SPG - 1 = GPW - 1; the SYNC step's own DMA is issued AFTER it crossed the boundary) - plus the interval's X stores,
+    // interleaved with them in any order. Boundary i + 1 needs group i + 1 landed: its DMAs were issued in interval i - 1, i.e. they
+    // are older than EVERY operation of interval i. Hence N = GPW + X is exact, any N <= GPW + X is safe (waits for more than
+    // necessary), and N > GPW + X would let a DMA of the group about to be read stay in flight. EXTRA must therefore be a LOWER
+    // bound of the stores of every interval that ends in the part (lds_part derives it; it does not depend on the refill form
+    // nor on where inside a step the stores stand - NF_LDS_TRAIN_K0).
     template <int EXTRA = 0>
     __device__ __forceinline__ void boundary() const {
         static_assert((C::S - 2) * C::GPW + EXTRA <= 63, "vmcnt is a 6-bit counter");
@@ -354,7 +370,7 @@ __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook
                     }
                 }
             };
-            constexpr int K0 = 4 * HSP >= 8 ? 4 : 0;                 // behind MFMAs 4..7 (a one-tile step has only 0..3)
+            constexpr int K0 = 4 * HSP >= 8 ? (4 * HSP >= NF_LDS_TRAIN_K0 + 4 ? NF_LDS_TRAIN_K0 : 4) : 0;   // behind MFMAs 4..7 (a one-tile step has only 0..3)
             auto post = [&](int k) {
                 if constexpr (!std::is_same<TStore, NoStore>::value) {
                     if (sp == 0 && k >= K0 && k < K0 + 4) {
@@ -363,14 +379,13 @@ __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook
                     }
                 }
             };
-            // Training stores of a part: 4 per quad, all issued AFTER the refill DMAs of the group interval they fall into
-            // (the DMAs stand behind the first MFMAs of the interval's first step, which carries no store), and every
-            // interval that ends inside this part holds exactly 4 * (quads per group) of them. They may therefore stay in
-            // flight across the boundary together with the youngest group - otherwise every boundary would wait for
-            // stores issued ~1.7 us earlier to be acknowledged.
-            // Counting them: the vm operations younger than the group a boundary waits for are the refill DMAs of
-            // the youngest group (GPW, issued behind the first MFMAs of the SYNC step that crossed the previous boundary) plus the
-            // stores of the steps from that SYNC step up to this boundary. SPQ == 2 (W = 256 full-width layers): the SYNC step is
+            // Training stores of a part: 4 per quad, on the quad's first step. They may stay in flight across a boundary
+            // together with the youngest group's DMAs (WRing::boundary: vmcnt(GPW + EXTRA), EXTRA = a lower bound of the stores
+            // issued in the interval that ends at the boundary) - otherwise every boundary would wait for stores issued ~1.7 us
+            // earlier to be acknowledged.
+            // Counting them (re-derived for the spread refill in round 6 - the count is the same for both refill
+            // forms): the interval that ends at a boundary of this part runs from the SYNC step that crossed the previous
+            // boundary up to (not including) the SYNC step at this one. SPQ == 2 (W = 256 full-width layers): the SYNC step is
             // the store-less second step of a quad, the GP/OT quads in between each carry 4 stores on their first step -> 4*GP/OT
             // whatever part came before. SPQ == 1 (W <= 128, and the W/2-wide views part at W = 256): every step carries stores,
             // also the SYNC step itself - which belongs to the PREVIOUS part at a part's first boundary, and that part may be a
@@ -379,6 +394,9 @@ __device__ __forceinline__ void lds_part(Ring& st, f32x16 (&acc)[NIN], Hook hook
             // acknowledged - free in practice), so that never a DMA of the group about to be read is still outstanding.
             constexpr int EXTRA = std::is_same<TStore, NoStore>::value ? 0 : 4 * (C::GP / OT - (SPQ == 1 ? 1 : 0));
             static_assert(EXTRA >= 0, "a store-carrying part spans at least one quad per group");
+            static_assert(std::is_same<TStore, NoStore>::value || SPQ == 1 || (C::GP / OT) * SPQ == C::SPG || !Ring::kSpreadDma,
+                          "spread refill: an interval is SPG full-width steps = GP / OT quads of SPQ steps, 4 stores on each quad's first");
+
             const int J = Ring::kSpreadDma ? (done / HSP) % C::SPG : 0;        // (done / HSP - 1 is this step's index in the part)
             if (done % C::GP == 0) st.template step<HSP, true, EXTRA>(J, pr, mid, mf, post);
             else st.template step<HSP, false>(J, pr, mid, mf, post);
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
     const float* const c_alpha = cst + (L.alpha_off - L.b_off[0]);
     const float* const c_rgb = cst + (L.rgb_off - L.b_off[0]);
 
-    WRing<NT, NF_LDS_SPREAD == 1 && !TRAIN, !TRAIN || NF_LDS_TRAIN_NEWDMA> st;
+    WRing<NT, NF_LDS_SPREAD == 1 && (!TRAIN || NF_LDS_TRAIN_SP1), !TRAIN || NF_LDS_TRAIN_NEWDMA> st;
     st.gsrc = a.packed + lane * 4; st.ring = ring0; st.rl = ring0 + lane * 4;
     st.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, (int)(L.w_total * 4), 0x00020000);   // raw buffer: the weight range
     st.voff = lane * 16;

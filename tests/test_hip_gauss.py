@@ -794,3 +794,59 @@ def test_original_logits_are_cached_by_default_for_named_views():
     assert calls == [3, 3, 3, 3]
     victim[4].weight.requires_grad_(False)
     G._VIEW_CACHE.clear(); G._VIEW_MAPS.clear(); G._VIEW_ORI.clear()
+
+
+@pytest.mark.parametrize('layout', ['random', 'few_long_rows', 'one_row', 'runs'])
+@pytest.mark.parametrize('targeted,eps', [(False, None), (True, 24.0)])
+def test_fused_sign_step_equals_the_separate_kernels(layout, targeted, eps):
+    """Round 6. On one rank nerfail_s_step runs K11 with the sign step as the epilogue of its last launch
+    (nerfail_gauss_bwd_views_rgb_step). Every bit stays as it was: the fused step == rgb gradient + igsm_step_rgb == the
+    four-channel autograd path, on index layouts that make rows cross one, several and all 512-entry chunks."""
+    from nerfail_amd import GaussNet as G, attack as A
+    rs = np.random.RandomState(31)
+    P_, B, H, W = 3, 3, 40, 36                                    # 1 440 pixels x 8 = 11 520 entries per view: 23 chunks
+    Ns = P_ * H * W
+    s0 = rs.uniform(-40, 40, size=(P_, H, W, 4)).astype(np.float32)
+    s0[..., 3] = np.where(rs.uniform(size=(P_, H, W)) < 0.8, 255.0, 0.0)
+    ori_u8 = synth.disc_alpha_image(B, H, W, seed=32).astype(np.uint8)
+    dist = np.sort(np.abs(rs.normal(scale=0.02, size=(B, H, W, 8))).astype(np.float32), -1)
+    if layout == 'random':
+        idx = rs.randint(0, Ns, size=(B, H, W, 8))
+    elif layout == 'few_long_rows':                               # 7 rows of ~1 600 entries each: every row spans 3-4 chunks
+        idx = rs.randint(0, 7, size=(B, H, W, 8)) * 601
+    elif layout == 'one_row':                                     # ONE row holds all entries of a view: head / middle / tail records only
+        idx = np.full((B, H, W, 8), 1234)
+    else:                                                         # runs of 300-700 entries: most rows cross exactly one boundary
+        idx = (np.arange(B * H * W * 8).reshape(B, H, W, 8) // rs.randint(300, 700)) % Ns
+    wi, _ = G.create_gauss_w(dev(), 0.02)(T(np.stack([dist, idx.astype(np.float32)], 1)))
+    torch.manual_seed(5)
+    victim = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(2), torch.nn.Flatten(),
+                                 torch.nn.Linear(16, 8)).to(dev()).requires_grad_(False)
+    with torch.no_grad():
+        victim[0].weight.mul_(0.05)                               # logits O(1): a real gradient
+    net = G.gauss_net(dev(), 0.02, victim, 'my_model', epsilon=eps)
+    label = torch.tensor(3, device=dev())
+    s0t, ori = T(s0), torch.from_numpy(ori_u8).to(dev())
+    s_init = T(s0 * 0.5)
+    g_full, loss_full, _ = A.perturbation_grad(net, s0t, wi, ori.float(), label)              # four channels, combine kernel
+    buf, _ = A.perturbation_grad_rgb(net, s0t, wi, ori, label)                                # rgb form
+    assert float(g_full.abs().max()) > 1e-8
+    assert torch.equal(buf[:3 * Ns].view(Ns, 3), g_full.reshape(Ns, 4)[:, :3].contiguous()), layout
+    ref = A.igsm_step_rgb(s0t, buf, s_init, 2.0, 32.0, targeted)
+    fused, loss = A.perturbation_step_rgb(net, s0t, s_init, wi, ori, label, 2.0, 32.0, targeted)
+    assert torch.equal(fused.view(-1), ref.view(-1)) and float(loss) == float(loss_full), layout
+    # the product's step function: fused on one rank, switchable
+    a1, l1 = A.nerfail_s_step(net, s0t, s_init, wi, ori, label, 2.0, 32.0, targeted)
+    net.fused_sign_step = False
+    a2, l2 = A.nerfail_s_step(net, s0t, s_init, wi, ori, label, 2.0, 32.0, targeted)
+    assert torch.equal(a1, a2) and torch.equal(a1.view(-1), ref.view(-1)) and float(l1) == float(l2)
+    # the gradient on request, next to the step
+    xr, cla, _, views, aux = net.attack_forward(s0t, wi, ori, None)
+    torch.nn.functional.cross_entropy(cla, label.broadcast_to([B]), reduction='sum').div(B).backward()
+    gout = torch.empty((3 * Ns,), device=dev())
+    again = G.hot_backward_rgb_step(aux, xr.grad, views, s0t, s_init, 2.0, 32.0, targeted, grad_out=gout)
+    assert torch.equal(again.view(-1), ref.view(-1)) and torch.equal(gout, buf[:3 * Ns])
+    # repeatable
+    for _ in range(2):
+        f2, _ = A.perturbation_step_rgb(net, s0t, s_init, wi, ori, label, 2.0, 32.0, targeted)
+        assert torch.equal(f2, fused)

@@ -65,22 +65,25 @@ EXPERIMENTS = {
          '            o_[0] = (unsigned)(c1_ - c0_); o_[1] = (unsigned)(c2_ - c1_); o_[2] = (unsigned)(c3_ - c2_); o_[3] = (unsigned)(c4_ - c3_);\n'
          '            o_[4] = __float_as_uint(rgb[0] + rgb[1] + rgb[2] + alpha); o_[5] = (unsigned)wall_clock64();\n'
          '        }\n')], []),
-    # wall-clock (100 MHz) stamps of a launch's phases per wave -> raw as 16 uint64 per wave: [0] kernel entry, [1] constants in LDS,
-    # [2] ring started, [3 + r] end of round r's tile (r < 12), [15] kernel end (tools/lds_timeline.py; outputs destroyed)
+    # wall-clock (100 MHz) stamps of a launch's phases per wave -> raw as 32 uint64 per wave: [0] kernel entry, [1] constants in LDS,
+    # [2] ring started, [3 + r] end of round r's tile (r < 12), [15] kernel end; [16 + i]: the shader clock (s_memtime) at the same
+    # points i = 2, 3 + r, 15 (tools/lds_timeline.py; outputs destroyed)
     'lds_timeline': ('mlp_lds.hip', [
         ('    const MlpLayout& L = a.lay;\n#if NF_LDS_RING_FIRST\n',
          '    const MlpLayout& L = a.lay;\n    const unsigned long long tl0_ = wall_clock64();\n#if NF_LDS_RING_FIRST\n'),
         ('    __syncthreads();\n    const float* const c_alpha = cst + (L.alpha_off - L.b_off[0]);\n',
          '    __syncthreads();\n    const unsigned long long tl1_ = wall_clock64();\n    const float* const c_alpha = cst + (L.alpha_off - L.b_off[0]);\n'),
         ('    st.start();\n\n    // Two activation arrays swap roles',
-         '    st.start();\n    const unsigned long long tl2_ = wall_clock64();\n\n    // Two activation arrays swap roles'),
+         '    st.start();\n    const unsigned long long tl2_ = wall_clock64(), tc2_ = clock64();\n\n    // Two activation arrays swap roles'),
         ('        if (h == 0 && sout < a.M && tile_own < ntiles)\n'
          '            reinterpret_cast<float4*>(a.raw)[sout] = make_float4(rgb[0], rgb[1], rgb[2], alpha);\n',
-         '        if (lane == 0 && rnd < 12 && sout < a.M + 64)\n'
-         '            (reinterpret_cast<unsigned long long*>(a.raw) + (blockIdx.x * 4 + wave) * 16)[3 + rnd] = wall_clock64() + (rgb[0] + rgb[1] + rgb[2] + alpha == 123.25f ? 1 : 0);\n'),
+         '        if (lane == 0 && rnd < 12 && sout < a.M + 64) {\n'
+         '            unsigned long long* o_ = reinterpret_cast<unsigned long long*>(a.raw) + (blockIdx.x * 4 + wave) * 32;\n'
+         '            o_[3 + rnd] = wall_clock64() + (rgb[0] + rgb[1] + rgb[2] + alpha == 123.25f ? 1 : 0);\n'
+         '            o_[16 + 3 + rnd] = clock64();\n        }\n'),
         ('    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight',
          '    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight\n'
-         '    if (lane == 0) { unsigned long long* o_ = reinterpret_cast<unsigned long long*>(a.raw) + (blockIdx.x * 4 + wave) * 16; o_[0] = tl0_; o_[1] = tl1_; o_[2] = tl2_; o_[15] = wall_clock64(); }\n    //')], []),
+         '    if (lane == 0) { unsigned long long* o_ = reinterpret_cast<unsigned long long*>(a.raw) + (blockIdx.x * 4 + wave) * 32; o_[0] = tl0_; o_[1] = tl1_; o_[2] = tl2_; o_[15] = wall_clock64(); o_[16 + 2] = tc2_; o_[16 + 15] = clock64(); }\n    //')], []),
     'lds_nobias': ('mlp_lds.hip', [('            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1, !decltype(out_is_p)::value); };\n', '            auto hk = [&](int q) {};\n'),
                                    ('            bias_tile(in, l + 1, NT - 1, !decltype(out_is_p)::value);\n', '')], []),
     'lds_norelu': ('mlp_lds.hip', [('b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);', 'b[e] = in[q >> 2][4 * (q & 3) + e];')], []),
@@ -96,6 +99,11 @@ EXPERIMENTS = {
     'bwd_sp0': ('mlp_lds.hip', [], ['-DNF_LDS_BWD_SP1=0']),
     'lds_train_newdma': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_NEWDMA=1']),
     'lds_midsplit': ('mlp_lds.hip', [], ['-DNF_LDS_MID_SPLIT=1']),
+    # round 6: the training forward on the one-piece-of-side-work-per-shadow step form; activation stores behind MFMAs K0 .. K0 + 3
+    'lds_train_sp1': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_SP1=1']),
+    'lds_train_sp1_k8': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_SP1=1', '-DNF_LDS_TRAIN_K0=8']),
+    'lds_train_sp1_k12': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_SP1=1', '-DNF_LDS_TRAIN_K0=12']),
+    'lds_train_k8': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_K0=8']),
     'lds_spread0': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=0']),
     'lds_spread2': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=2']),
     'lds_spread_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27776']),
