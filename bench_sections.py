@@ -104,8 +104,8 @@ def kernel_source_hash():
 KERNEL_SOURCES = {'nerf_mlp_fwd_lds_kernel': ('mlp_lds.hip', 'mlp_layout.h', 'common.h'),
                   'gauss_': ('gauss.hip', 'gauss_csr.hip', 'common.h'), 'igsm_': ('gauss.hip', 'common.h'),
                   'seg_': ('gauss_csr.hip', 'common.h')}
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_hbm_traffic.json')
-PMC_SQ_FILE = os.path.join(ROOT, 'profiles', 'r05_pmc_sq_render.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r06_pmc_hbm_traffic.json')
+PMC_SQ_FILE = os.path.join(ROOT, 'profiles', 'r06_pmc_sq_render.json')
 
 
 def _kernel_key(name):
@@ -117,7 +117,7 @@ def _kernel_key(name):
 
 
 def pmc_mfma_busy(kernel):
-    """Matrix-pipe utilisation of a kernel from the stored SQ counter pass (tools/r05_pmc_sq.sh: SQ_VALU_MFMA_BUSY_CYCLES over the
+    """Matrix-pipe utilisation of a kernel from the stored SQ counter pass (tools/r06_pmc_sq.sh: SQ_VALU_MFMA_BUSY_CYCLES over the
     SIMD-cycles of the dispatch, and the clock the chip held) - reported only while the kernel's sources are unchanged."""
     try:
         pmc = json.load(open(PMC_SQ_FILE))
