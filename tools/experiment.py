@@ -84,6 +84,33 @@ EXPERIMENTS = {
         ('    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight',
          '    lds_wait_vmcnt<0>();       // no LDS-DMA may be in flight\n'
          '    if (lane == 0) { unsigned long long* o_ = reinterpret_cast<unsigned long long*>(a.raw) + (blockIdx.x * 4 + wave) * 32; o_[0] = tl0_; o_[1] = tl1_; o_[2] = tl2_; o_[15] = wall_clock64(); o_[16 + 2] = tc2_; o_[16 + 15] = clock64(); }\n    //')], []),
+    # round 6, pricing of VERDICT r5 item 6 (the per-ray-constant view channels folded into the views layer's bias): the 64 MFMAs of
+    # the direction part become ring skips, and a stand-in for the fold's own work is added per tile - all 12 direction bands
+    # evaluated as (sin, cos) pairs, a 2-channel x 27 dot product per lane with its weights read from LDS. The lane's own 12 direction band values are still computed (the real fold would not): the build UNDERSTATES the gain by
+    # ~1 k of a tile's 633 k cycles. Wrong results on purpose - timing only.
+    'lds_fold_price': ('mlp_lds.hip', [
+        ('        lds_part<NT, OTV, kDirQuads, C::kStreamPad>(st, Q, [](int) {}, [&](int q, float (&b)[4]) { b_park(kEmbQuads + q, b); });\n',
+         '        lds_part<NT, OTV, 0, kDirQuads * OTV + C::kStreamPad>(st, Q, [](int) {}, [&](int q, float (&b)[4]) { b_park(kEmbQuads + q, b); });\n'),
+        ('        encode_sample(a, s, hh, emb, demb);\n',
+         '        encode_sample(a, s, hh, emb, demb);\n'
+         '        if (a.rays != nullptr) {\n'
+         '            const float* ray_ = a.rays + NERFAIL_RAY_FLOATS * (s / a.spr);\n'
+         '            float gm_[27];\n'
+         '#pragma unroll\n'
+         '            for (int d = 0; d < 3; ++d) {\n'
+         '                const SinCosBands sc_(ray_[8 + d]);\n'
+         '                gm_[d] = ray_[8 + d];\n'
+         '#pragma unroll\n'
+         '                for (int f = 0; f < 4; ++f) sc_.band(f, gm_[3 + 6 * f + d], gm_[6 + 6 * f + d]);\n'
+         '            }\n'
+         '            float c0_ = cst[lane], c1_ = cst[64 + lane];\n'
+         '#pragma unroll\n'
+         '            for (int jx = 0; jx < 27; ++jx) {\n'
+         '                const float2 w_ = *reinterpret_cast<const float2*>(cst + 256 + jx * 128 + 2 * lane);\n'
+         '                c0_ = fmaf(w_.x, gm_[jx], c0_); c1_ = fmaf(w_.y, gm_[jx], c1_);\n'
+         '            }\n'
+         '            emb[31] += (c0_ + c1_) * 1e-30f;      // (kept alive: the stand-in must not be optimised away)\n'
+         '        }\n')], []),
     'lds_nobias': ('mlp_lds.hip', [('            auto hk = [&](int q) { if ((q & 3) == 0 && q > 0) bias_tile(in, l + 1, (q >> 2) - 1, !decltype(out_is_p)::value); };\n', '            auto hk = [&](int q) {};\n'),
                                    ('            bias_tile(in, l + 1, NT - 1, !decltype(out_is_p)::value);\n', '')], []),
     'lds_norelu': ('mlp_lds.hip', [('b[e] = relu_bits(in[q >> 2][4 * (q & 3) + e]);', 'b[e] = in[q >> 2][4 * (q & 3) + e];')], []),
