@@ -630,9 +630,12 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
                 lds_part<NT, NT, 4 * NT, 0>(st, out, hk, bp, [&](int q, int e, const float (&b)[4]) {
                     const int r = 4 * (q & 3) + e;
                     st_acc_reg(Hl + (q >> 2) * 1024, voff, r, b[e]);
-                    mk16 |= relu_bit(b[e]) << r;
+                    // this value's ReLU bit appended: compare into VCC, then mk16 = 2 mk16 + carry (the 16 bits of a tile arrive in
+                    // the order r = 0 .. 15, so they end up reversed: one v_bfrev per tile). Round 6: 0.8 % of the training forward
+                    // against v_med3_i32 + v_lshl_or_b32 (profiles/r06_train_mask_ab.log); same bits as relu_bit() << r.
+                    asm volatile("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mk16) : "v"(b[e]) : "vcc");
                     if (r == 15) {
-                        st_mask16(Ml, vlane16, q >> 2, mk16);
+                        st_mask16(Ml, vlane16, q >> 2, __builtin_bitreverse32(mk16) >> 16);
                         mk16 = 0u;
                     }
                 });
@@ -676,9 +679,9 @@ __global__ __launch_bounds__(256, 1) void nerf_mlp_fwd_lds_kernel(MlpArgs a) {
                     asm("" : "+v"(v));
                     v = relu_bits(v);
                     st_acc_reg(Vl + t * 1024, voff, r, v);
-                    mv |= relu_bit(v) << r;
+                    asm volatile("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mv) : "v"(v) : "vcc");   // (as in layer())
                 }
-                st_mask16(Amask + L.D * 256, vlane16, t, mv);
+                st_mask16(Amask + L.D * 256, vlane16, t, __builtin_bitreverse32(mv) >> 16);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (OTV & 1) st_mask16(Amask + L.D * 256, vlane16, OTV, 0u);                 // the dword's unused half, as store_mask writes it

@@ -131,6 +131,30 @@ EXPERIMENTS = {
     'lds_train_sp1_k8': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_SP1=1', '-DNF_LDS_TRAIN_K0=8']),
     'lds_train_sp1_k12': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_SP1=1', '-DNF_LDS_TRAIN_K0=12']),
     'lds_train_k8': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_K0=8']),
+    # round 6, the ReLU bit masks of the training forward (4.2 % of it): other instruction pairs for "append this value's bit"
+    'lds_mask_cmp': ('mlp_lds.hip', [
+        ('                    mk16 |= relu_bit(b[e]) << r;\n                    if (r == 15) {\n',
+         '                    asm volatile("v_cmp_lt_i32 vcc, 0, %1\\n\\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mk16) : "v"(b[e]) : "vcc");\n'
+         '                    if (r == 15) {\n                        mk16 = __builtin_bitreverse32(mk16) >> 16;\n')], []),
+    # round 6: the backward-data ring kernel's lazy masking with the bits shifted out through VCC (v_add_co + v_cndmask) instead of
+    # v_bfe_i32 + v_and_b32
+    'bwd_mask_carry': ('mlp_lds.hip', [
+        ('            const TileMask<NT> m = mk;\n',
+         '            const TileMask<NT> m = mk;\n            unsigned mcur_ = 0u;\n'),
+        ('#pragma unroll\n                    for (int e = 0; e < 4; ++e) b[e] = mask_apply<NT>(m, q >> 2, 4 * (q & 3) + e, in[q >> 2][4 * (q & 3) + e]);\n',
+         '                    if ((q & 7) == 0) mcur_ = __builtin_bitreverse32(m.w[q >> 3]);\n'
+         '#pragma unroll\n'
+         '                    for (int e = 0; e < 4; ++e) {\n'
+         '                        float x_ = in[q >> 2][4 * (q & 3) + e];\n'
+         '                        asm volatile("v_add_co_u32 %0, vcc, %0, %0\\n\\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(mcur_), "+v"(x_) : : "vcc");\n'
+         '                        b[e] = x_;\n'
+         '                    }\n')], []),
+    'lds_mask_tree': ('mlp_lds.hip', [
+        ('            unsigned mk16 = 0u;                                                           // ReLU bits of the tile being consumed\n',
+         '            unsigned mk16 = 0u, mkq_[4] = {0u, 0u, 0u, 0u};\n'),
+        ('                    mk16 |= relu_bit(b[e]) << r;\n                    if (r == 15) {\n',
+         '                    mkq_[e] |= relu_bit(b[e]) << r;\n                    if (r == 15) {\n'
+         '                        mk16 = (mkq_[0] | mkq_[1]) | (mkq_[2] | mkq_[3]); mkq_[0] = mkq_[1] = mkq_[2] = mkq_[3] = 0u;\n')], []),
     'lds_spread0': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=0']),
     'lds_spread2': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=2']),
     'lds_spread_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27776']),
