@@ -149,7 +149,7 @@ def contract_line(detail, world, args, detail_path):
         'roofline': ({'kernel': rf.get('kernel'), 'bound': rf.get('bound'), 'achieved': _num(rf.get('achieved')),
                       'peak': rf.get('peak'), 'unit': rf.get('unit'), 'frac': _num(rf.get('frac')),
                       'traffic': _num(rf.get('traffic')), 'avg_launch_ms': _num(rf.get('avg_launch_ms')),
-                      'mfma_busy': _num(rf.get('mfma_busy'))} if rf else None),
+                      'mfma_busy': _num(rf.get('mfma_busy')), 'clock_GHz': _num(rf.get('clock_GHz'))} if rf else None),
         'cpu_baseline': ({'value': _num(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'),
                           'kind': cb.get('kind'), 'sample': str(cb.get('sample', ''))[:110]} if isinstance(cb, dict) else None),
         'rccl_ranks': detail.get('rccl_ranks'),

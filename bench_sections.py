@@ -1062,6 +1062,7 @@ def child_render(args, emit):
                          'traffic': traffic, 'traffic_unit': 'HBM+IC bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
                          'traffic_source': traffic_source,
                          'mfma_busy': (pmc_mfma_busy('nerf_mlp_fwd_lds_kernel<8,1,false>') or {}).get('mfma_busy'),
+                         'clock_GHz': (pmc_mfma_busy('nerf_mlp_fwd_lds_kernel<8,1,false>') or {}).get('clock_GHz'),   # the clock the chip held in that counter pass (the peak assumes 2.4)
                          'mfma_busy_source': pmc_mfma_busy('nerf_mlp_fwd_lds_kernel<8,1,false>'),
                          'launches': len(mlp_events), 'avg_launch_ms': mlp_ms / max(1, len(mlp_events)),
                          'flop_per_sample': FLOP_PER_SAMPLE, 'mlp_share_of_step': mlp_ms * 1e-3 / elapsed},
