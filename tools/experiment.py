@@ -131,11 +131,14 @@ EXPERIMENTS = {
     'lds_train_sp1_k8': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_SP1=1', '-DNF_LDS_TRAIN_K0=8']),
     'lds_train_sp1_k12': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_SP1=1', '-DNF_LDS_TRAIN_K0=12']),
     'lds_train_k8': ('mlp_lds.hip', [], ['-DNF_LDS_TRAIN_K0=8']),
-    # round 6, the ReLU bit masks of the training forward (4.2 % of it): other instruction pairs for "append this value's bit"
-    'lds_mask_cmp': ('mlp_lds.hip', [
-        ('                    mk16 |= relu_bit(b[e]) << r;\n                    if (r == 15) {\n',
-         '                    asm volatile("v_cmp_lt_i32 vcc, 0, %1\\n\\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mk16) : "v"(b[e]) : "vcc");\n'
-         '                    if (r == 15) {\n                        mk16 = __builtin_bitreverse32(mk16) >> 16;\n')], []),
+    # round 6, the ReLU bit masks of the training forward: the product appends a value's bit with v_cmp_lt_i32 + v_addc_co_u32
+    # (bits arrive reversed, one v_bfrev per tile). lds_mask_med3 = the idiom of rounds 3-5 (v_med3_i32 + v_lshl_or_b32): the A/B
+    # partner of profiles/r06_train_mask_ab.log (6.836 against 6.782 ms at 786 432 samples; same bits)
+    'lds_mask_med3': ('mlp_lds.hip', [
+        ('                    asm volatile("v_cmp_lt_i32 vcc, 0, %1\\n\\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mk16) : "v"(b[e]) : "vcc");\n'
+         '                    if (r == 15) {\n                        st_mask16(Ml, vlane16, q >> 2, __builtin_bitreverse32(mk16) >> 16);\n',
+         '                    mk16 |= relu_bit(b[e]) << r;\n'
+         '                    if (r == 15) {\n                        st_mask16(Ml, vlane16, q >> 2, mk16);\n')], []),
     # round 6: the backward-data ring kernel's lazy masking with the bits shifted out through VCC (v_add_co + v_cndmask) instead of
     # v_bfe_i32 + v_and_b32
     'bwd_mask_carry': ('mlp_lds.hip', [
@@ -149,12 +152,6 @@ EXPERIMENTS = {
          '                        asm volatile("v_add_co_u32 %0, vcc, %0, %0\\n\\tv_cndmask_b32 %1, 0, %1, vcc" : "+v"(mcur_), "+v"(x_) : : "vcc");\n'
          '                        b[e] = x_;\n'
          '                    }\n')], []),
-    'lds_mask_tree': ('mlp_lds.hip', [
-        ('            unsigned mk16 = 0u;                                                           // ReLU bits of the tile being consumed\n',
-         '            unsigned mk16 = 0u, mkq_[4] = {0u, 0u, 0u, 0u};\n'),
-        ('                    mk16 |= relu_bit(b[e]) << r;\n                    if (r == 15) {\n',
-         '                    mkq_[e] |= relu_bit(b[e]) << r;\n                    if (r == 15) {\n'
-         '                        mk16 = (mkq_[0] | mkq_[1]) | (mkq_[2] | mkq_[3]); mkq_[0] = mkq_[1] = mkq_[2] = mkq_[3] = 0u;\n')], []),
     'lds_spread0': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=0']),
     'lds_spread2': ('mlp_lds.hip', [], ['-DNF_LDS_SPREAD=2']),
     'lds_spread_steps': ('mlp_lds.hip', LDS_STEPS, ['-DNF_LDS_SPREAD=1', '-DNF_ST_LO=27776']),
@@ -182,7 +179,7 @@ EXPERIMENTS = {
                                           '    asm volatile("" ::"v"(voff), "v"(v), "s"(sbase) : "memory");\n')], []),
     'lds_train_nomask': ('mlp_lds.hip', [('    asm volatile("global_store_short %0, %1, %2 offset:%3" ::"v"(vlane16), "v"(bits), "s"(sentry), "i"(2 * t) : "memory");\n',
                                          '    asm volatile("" ::"v"(vlane16), "v"(bits), "s"(sentry) : "memory");\n'),
-                                        ('                    mk16 |= relu_bit(b[e]) << r;\n', '')], []),
+                                        ('                    asm volatile("v_cmp_lt_i32 vcc, 0, %1\\n\\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mk16) : "v"(b[e]) : "vcc");\n', '')], []),
     # pricing of the weight-gradient step loop (mlp_dw.hip): no LDS-DMA / no per-step barrier / no LDS operand reads / no row sums
     'dw_nodma': ('mlp_dw.hip', [('        __builtin_amdgcn_global_load_lds((glb_void_t*)(base + voff[i]),\n                                         (lds_void_t*)(smem + rs * kDwStageFloats + (wave + 4 * i) * 256), 16, 0, 0);\n',
                                  '        asm volatile("" :: "v"(base + voff[i]), "s"(rs));\n')], []),
