@@ -666,11 +666,13 @@ class gauss_net(nn.Module):
                 ori_key = (o.data_ptr(), o._version, tuple(o.shape))
                 ori_img = o
             ori_cla = self._ori_cla_cache.get(ori_key)
-            if ori_cla is None:
+            if ori_cla is not None:
+                ori_cla = ori_cla.clone()            # the caller owns what it gets (the reference's callers write into logits in place, deepfool.py:54-57)
+            else:
                 if len(self._ori_cla_cache) >= 64:
                     self._ori_cla_cache.clear()
                 ori_cla, o = ori_logits(False)
-                self._ori_cla_cache[ori_key] = ori_cla
+                self._ori_cla_cache[ori_key] = ori_cla.clone()       # (a private copy: the returned tensor is the caller's)
                 if ori_key[0] != 'ids':              # an address-based key: the address must not be recycled while the key lives
                     keep = getattr(self, '_ori_keep_src', None)
                     self._ori_cla_keep = getattr(self, '_ori_cla_keep', [])[-63:] + [o if keep is None else keep]

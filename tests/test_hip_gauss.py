@@ -759,6 +759,10 @@ def test_original_logits_are_cached_by_default_for_named_views():
     calls.clear()
     got5 = net(s0, wi, ori_d, view_ids=ids)                                          # the reference-shaped 5-tuple forward too
     assert calls == [3] and all(torch.equal(x, y) for x, y in zip(got5, ref5))
+    got5[4].add_(1000.)                                                              # the caller owns what it got (deepfool.py:54-57 writes
+    again5 = net(s0, wi, ori_d, view_ids=ids)                                        # into logits in place): the cache keeps its own copy
+    assert torch.equal(again5[4], ref5[4])
+    calls.clear()
     calls.clear()
     A.nerfail_s_step(net, s0, s0, wi, ori_d, label)                                  # no ids: never cached by default
     A.nerfail_s_step(net, s0, s0, wi, ori_d, label)
